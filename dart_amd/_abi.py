@@ -1,0 +1,134 @@
+"""ctypes binding of libdartk.so (include/dartk.h). The product path has NO fallback: if the HIP library is
+missing or fails to load, importing anything that needs it raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdartk.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int32)
+
+
+class DaPoint(C.Structure):
+    _fields_ = [("index", C.c_int32), ("dataAssociation", C.c_int32), ("error", C.c_float)]
+
+
+DA_DTYPE = np.dtype([("index", np.int32), ("dataAssociation", np.int32), ("error", np.float32)])
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("n_frames", C.c_int32), ("n_joints", C.c_int32), ("n_sdfs", C.c_int32), ("model_id", C.c_int32),
+        ("frame_parent", c_int_p), ("joint_type", c_int_p), ("joint_axis", c_float_p), ("T_pf", c_float_p),
+        ("dh", c_float_p), ("joint_limits", c_float_p), ("sdf_frame", c_int_p), ("dependencies", c_int_p),
+        ("sdf_dim", c_int_p), ("sdf_offset", c_float_p), ("sdf_resolution", c_float_p),
+        ("sdf_data", C.POINTER(c_float_p)),
+        ("obs_sdf_dim", C.c_int32 * 3), ("obs_sdf_offset", C.c_float * 3), ("obs_sdf_resolution", C.c_float),
+    ]
+
+
+def fptr(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+def iptr(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+def fill_model_desc(desc_cls, host_model, model_id=0, obs_layout=None):
+    """Build a ModelDesc-compatible ctypes struct (also used for the oracle's orc_model, same field order)
+    from a HostModel. Returns (desc, keepalive)."""
+    a = host_model.arrays()
+    keep = dict(a)
+    d = desc_cls()
+    d.n_frames, d.n_joints, d.n_sdfs, d.model_id = host_model.n_frames, host_model.n_joints, len(host_model.sdfs), model_id
+    d.frame_parent = iptr(a["frame_parent"])
+    d.joint_type = iptr(a["joint_type"])
+    d.joint_axis = fptr(a["joint_axis"])
+    d.T_pf = fptr(a["T_pf"])
+    d.dh = fptr(a["dh"])
+    d.joint_limits = fptr(a["joint_limits"])
+    d.sdf_frame = iptr(a["sdf_frame"])
+    d.dependencies = iptr(a["dependencies"])
+    d.sdf_dim = iptr(a["sdf_dim"])
+    d.sdf_offset = fptr(a["sdf_offset"])
+    d.sdf_resolution = fptr(a["sdf_resolution"])
+    arr = (c_float_p * len(a["sdf_data"]))(*[fptr(x) for x in a["sdf_data"]])
+    keep["_ptrs"] = arr
+    d.sdf_data = C.cast(arr, C.POINTER(c_float_p))
+    if obs_layout is not None:
+        dim, off, res = obs_layout
+        for k in range(3):
+            d.obs_sdf_dim[k] = int(dim[k])
+            d.obs_sdf_offset[k] = float(off[k])
+        d.obs_sdf_resolution = float(res)
+    return d, keep
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libdartk.so not built: run `python -m dart_amd.build` (the product path has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    L.dartk_last_error.restype = C.c_char_p
+    L.dartk_model_obs_sdf_data.restype = C.c_void_p
+    vp = C.c_void_p
+    sigs = {
+        "dartk_init": [C.c_int],
+        "dartk_buf_alloc": [C.POINTER(vp), C.c_size_t],
+        "dartk_buf_free": [vp],
+        "dartk_buf_h2d": [vp, vp, C.c_size_t, vp],
+        "dartk_buf_d2h": [vp, vp, C.c_size_t, vp],
+        "dartk_buf_zero": [vp, C.c_size_t, vp],
+        "dartk_stream_sync": [vp],
+        "dartk_model_create": [C.POINTER(ModelDesc), C.POINTER(vp)],
+        "dartk_model_destroy": [vp],
+        "dartk_model_set_pose": [vp, c_float_p, c_float_p, vp],
+        "dartk_model_set_articulation": [vp, c_float_p, vp],
+        "dartk_model_set_transforms": [vp, c_float_p, c_float_p, c_float_p, vp],
+        "dartk_model_get_transforms": [vp, c_float_p, c_float_p, c_float_p, c_float_p],
+        "dartk_model_num_sdfs": [vp],
+        "dartk_model_dims": [vp],
+        "dartk_model_obs_sdf_data": [vp],
+        "dartk_assoc_single": [vp, vp, C.c_int, C.c_int, vp, C.c_float, C.c_float, C.c_float, c_float_p, vp, vp, c_int_p, vp, vp, vp, vp],
+        "dartk_assoc_multi": [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), c_float_p, c_float_p, c_float_p, C.POINTER(vp), vp, vp, vp, vp],
+        "dartk_ne_obs2mod": [C.c_int, vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp],
+        "dartk_ne_obs2mod_reduced": [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp],
+        "dartk_ne_obs2mod_parammap": [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp],
+    }
+    for name, args in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        if name not in ("dartk_model_obs_sdf_data",):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def declared_symbols():
+    """Every `dartk_*` function name declared in include/dartk*.h (used by the CPU symbol-export test)."""
+    import re
+    inc = os.path.join(_HERE, "..", "include")
+    names = set()
+    for f in os.listdir(inc):
+        if f.endswith(".h"):
+            txt = open(os.path.join(inc, f)).read()
+            names.update(re.findall(r"\b(dartk_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
+
+
+class DartkError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise DartkError("dartk error %d: %s" % (rc, lib().dartk_last_error().decode()))

@@ -1,0 +1,243 @@
+// dartk_internal.h -- device-side data layout and helpers shared by the dartk HIP translation units.
+//
+// HBM layout of one model (a single arena, see dartk_model.hip):
+//   [static]  SdfDev sdfs[nSdfs] | int sdfFrame[] | u64 depMask[nFrames] | int jointType[] | float jointAxis[3*nJ]
+//             | float T_pf[12*nJ] | float dh[4*nJ] | float limits[2*nJ] | int frameParent[] | int dependencies[]
+//   [pose]    float T_mc[12] | T_cm[12] | T_mf[12*nFrames] | T_fm[12*nFrames] | joints[nJ]
+//   [grids]   all SDF voxel data back to back (voxel units, x fastest, 256-B aligned per grid) | obs SDF
+// Kernels receive a ModelView by value (pointers into the arena). Indices that are wave-uniform (the loop
+// over SDFs, the loop over joints) are read through the scalar cache; per-lane-divergent transform lookups
+// (the associated SDF's frame) are served from an LDS copy staged once per workgroup.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dartk.h"
+
+namespace dartk {
+
+struct SdfDev {               // 64 bytes
+    int dimx, dimy, dimz;
+    int dataOff;              // offset (in floats) of this grid in the model's grid arena
+    float ox, oy, oz, res;
+    // exact float images of the reference's double-literal bound tests (grid_3d.h:63-80):
+    //   p > 2.50001  <=>  p >= lo25 ;   p < dim - 2.50001  <=>  p <= hi25{x,y,z}
+    float lo25, hi25x, hi25y, hi25z;
+    float lo05, hi05x, hi05y, hi05z;
+};
+
+struct ModelView {
+    int nFrames, nJoints, nSdfs, modelId;
+    const SdfDev *sdfs;
+    const int *sdfFrame;
+    const unsigned long long *depMask;
+    const int *jointType;
+    const float *jointAxis;
+    const float *T_pf;
+    const float *dh;
+    const float *limits;
+    const int *frameParent;
+    const float *grids;
+    float *T_mc;      // [12] camera -> model
+    float *T_cm;      // [12]
+    float *T_mf;      // [12*nFrames] frame -> model
+    float *T_fm;      // [12*nFrames] model -> frame
+    float *joints;    // [nJoints] (clamped)
+    SdfDev obs;       // observation SDF header (dataOff unused)
+    float *obsData;
+};
+
+struct Model {        // host-side handle (dartk_model_t)
+    ModelView v;
+    void *arena;
+    size_t arenaBytes;
+    int device;
+    // host copies needed by wrappers
+    float *h_pin;     // pinned staging for pose uploads
+    size_t obsVoxels;
+    float *dtTmp;     // obs-SDF distance transform scratch (generateObsSdf)
+};
+
+// ---- error handling -------------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+#define DARTK_HIP(call)                                                                      \
+    do {                                                                                     \
+        hipError_t _e = (call);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            dartk::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return DARTK_ERR_HIP;                                                            \
+        }                                                                                    \
+    } while (0)
+#define DARTK_REQUIRE(cond, ...)                                                             \
+    do {                                                                                     \
+        if (!(cond)) { dartk::set_error(__VA_ARGS__); return DARTK_ERR_INVALID; }            \
+    } while (0)
+
+// per-device workspace: partial-system slabs for the deterministic two-pass reductions
+struct Workspace {
+    float *partials;       // [maxBlocks][maxSys]
+    size_t partialFloats;
+    int *counters;         // small int scratch
+    float *sysScratch;     // packed systems (device GN loop)
+};
+int get_workspace(Workspace **ws);
+static constexpr int kMaxPartialBlocks = 2048;
+static constexpr int kMaxDims = 70;                       // 6 + DARTK_MAX_JOINTS
+static constexpr int kMaxSys = (kMaxDims + 1) * (kMaxDims + 2) / 2;
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- device helpers -------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+struct f3 { float x, y, z; };
+
+// SE3Transform(A, float4 b) with b.w carried (SE3.h:411-416): keeps the reference's left-to-right sums.
+__device__ __forceinline__ f3 se3_apply_w(const float *A, float bx, float by, float bz, float bw) {
+    f3 o;
+    o.x = A[0] * bx + A[1] * by + A[2] * bz + A[3] * bw;
+    o.y = A[4] * bx + A[5] * by + A[6] * bz + A[7] * bw;
+    o.z = A[8] * bx + A[9] * by + A[10] * bz + A[11] * bw;
+    return o;
+}
+// SE3Transform(A, float3 b) (SE3.h:435-439)
+__device__ __forceinline__ f3 se3_apply(const float *A, f3 b) {
+    f3 o;
+    o.x = A[0] * b.x + A[1] * b.y + A[2] * b.z + A[3];
+    o.y = A[4] * b.x + A[5] * b.y + A[6] * b.z + A[7];
+    o.z = A[8] * b.x + A[9] * b.y + A[10] * b.z + A[11];
+    return o;
+}
+// SE3Rotate (SE3.h:441-445)
+__device__ __forceinline__ f3 se3_rotate(const float *A, f3 b) {
+    f3 o;
+    o.x = A[0] * b.x + A[1] * b.y + A[2] * b.z;
+    o.y = A[4] * b.x + A[5] * b.y + A[6] * b.z;
+    o.z = A[8] * b.x + A[9] * b.y + A[10] * b.z;
+    return o;
+}
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+    f3 o;
+    o.x = a.y * b.z - a.z * b.y;
+    o.y = a.z * b.x - a.x * b.z;
+    o.z = a.x * b.y - a.y * b.x;
+    return o;
+}
+// SE3Transform(A,B) (SE3.h:396-409) and SE3Invert (:447-451) on float[12]
+__device__ __forceinline__ void se3_mul(const float *A, const float *B, float *o) {
+    float r[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float a0 = A[4 * i], a1 = A[4 * i + 1], a2 = A[4 * i + 2], a3 = A[4 * i + 3];
+        r[4 * i + 0] = a0 * B[0] + a1 * B[4] + a2 * B[8];
+        r[4 * i + 1] = a0 * B[1] + a1 * B[5] + a2 * B[9];
+        r[4 * i + 2] = a0 * B[2] + a1 * B[6] + a2 * B[10];
+        r[4 * i + 3] = a0 * B[3] + a1 * B[7] + a2 * B[11] + a3;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) o[i] = r[i];
+}
+__device__ __forceinline__ void se3_invert(const float *A, float *o) {
+    float r[12];
+    r[0] = A[0]; r[1] = A[4]; r[2] = A[8];   r[3]  = -(A[0] * A[3] + A[4] * A[7] + A[8] * A[11]);
+    r[4] = A[1]; r[5] = A[5]; r[6] = A[9];   r[7]  = -(A[1] * A[3] + A[5] * A[7] + A[9] * A[11]);
+    r[8] = A[2]; r[9] = A[6]; r[10] = A[10]; r[11] = -(A[2] * A[3] + A[6] * A[7] + A[10] * A[11]);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) o[i] = r[i];
+}
+
+// ---- Grid3D lookups (grid_3d.h). All of this is exact fp32: for 0.5 <= p < 2^23 the reference's double
+// expressions (p - 0.5), (int)(p - 0.5) and the fraction are exactly representable in fp32, so evaluating
+// them in fp32 gives bit-identical x0 / fx (DESIGN.md "mixed precision"); the double-literal bound tests
+// are replaced by their exact float images precomputed on the host.
+__device__ __forceinline__ f3 grid_coords(const SdfDev &s, f3 p) {        // grid_3d.h:49-51
+    f3 g;
+    g.x = (p.x - s.ox) / s.res;
+    g.y = (p.y - s.oy) / s.res;
+    g.z = (p.z - s.oz) / s.res;
+    return g;
+}
+__device__ __forceinline__ bool in_bounds_grad_interp(const SdfDev &s, f3 g) {  // grid_3d.h:76-80
+    return g.x >= s.lo25 && g.x <= s.hi25x && g.y >= s.lo25 && g.y <= s.hi25y && g.z >= s.lo25 && g.z <= s.hi25z;
+}
+__device__ __forceinline__ bool in_bounds_interp(const SdfDev &s, f3 g) {       // grid_3d.h:63-67
+    return g.x >= s.lo05 && g.x <= s.hi05x && g.y >= s.lo05 && g.y <= s.hi05y && g.z >= s.lo05 && g.z <= s.hi05z;
+}
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return a + t * (b - a); }
+
+// getValueInterpolated (grid_3d.h:86-112); data points at voxel (0,0,0) of the grid
+__device__ __forceinline__ float grid_value(const float *__restrict__ data, int dimx, int dimy, f3 g) {
+    const float tx = g.x - 0.5f, ty = g.y - 0.5f, tz = g.z - 0.5f;
+    const int x0 = (int)tx, y0 = (int)ty, z0 = (int)tz;
+    const float fx = tx - (float)x0, fy = ty - (float)y0, fz = tz - (float)z0;
+    const float *p = data + (x0 + dimx * (y0 + dimy * z0));
+    const int sy = dimx, sz = dimx * dimy;
+    const float v000 = p[0], v100 = p[1];
+    const float v010 = p[sy], v110 = p[sy + 1];
+    const float v001 = p[sz], v101 = p[sz + 1];
+    const float v011 = p[sz + sy], v111 = p[sz + sy + 1];
+    const float dx00 = lerpf(v000, v100, fx);
+    const float dx01 = lerpf(v001, v101, fx);
+    const float dx10 = lerpf(v010, v110, fx);
+    const float dx11 = lerpf(v011, v111, fx);
+    const float dxy0 = lerpf(dx00, dx10, fy);
+    const float dxy1 = lerpf(dx01, dx11, fy);
+    return lerpf(dxy0, dxy1, fz);
+}
+// getGradientInterpolated (grid_3d.h:314-330): six interpolated lookups at +-1 voxel, 0.5*(f+ - f-)
+__device__ __forceinline__ f3 grid_gradient(const float *__restrict__ data, int dimx, int dimy, f3 g) {
+    f3 q, r;
+    q = g; q.x = g.x + 1.0f; const float fpx = grid_value(data, dimx, dimy, q);
+    q = g; q.y = g.y + 1.0f; const float fpy = grid_value(data, dimx, dimy, q);
+    q = g; q.z = g.z + 1.0f; const float fpz = grid_value(data, dimx, dimy, q);
+    q = g; q.x = g.x - 1.0f; const float fmx = grid_value(data, dimx, dimy, q);
+    q = g; q.y = g.y - 1.0f; const float fmy = grid_value(data, dimx, dimy, q);
+    q = g; q.z = g.z - 1.0f; const float fmz = grid_value(data, dimx, dimy, q);
+    r.x = 0.5f * (fpx - fmx);
+    r.y = 0.5f * (fpy - fmy);
+    r.z = 0.5f * (fpz - fmz);
+    return r;
+}
+
+// ---- articulated Jacobian (kernel_common.h:12-71) ---------------------------------------------------
+// Writes J[0..dims) (or the nJoints articulation entries when ARTIC_ONLY) with stride 1 into `J`.
+// T_fm / T_mf may point to LDS or global memory. depMask = this frame's kinematic-chain bit mask.
+template <bool ARTIC_ONLY>
+__device__ __forceinline__ void error_jacobian(float *J, f3 pm, float pw, unsigned long long depMask, f3 grad,
+                                               int nJoints, const int *__restrict__ jointType,
+                                               const float *__restrict__ jointAxis, const float *T_fm,
+                                               const float *T_mf) {
+    float *Ja = J;
+    if (!ARTIC_ONLY) {
+        J[0] = grad.x * -1.0f + grad.y * 0.0f + grad.z * 0.0f;
+        J[1] = grad.x * 0.0f + grad.y * -1.0f + grad.z * 0.0f;
+        J[2] = grad.x * 0.0f + grad.y * 0.0f + grad.z * -1.0f;
+        J[3] = grad.x * 0.0f + grad.y * pm.z + grad.z * -pm.y;
+        J[4] = grad.x * -pm.z + grad.y * 0.0f + grad.z * pm.x;
+        J[5] = grad.x * pm.y + grad.y * -pm.x + grad.z * 0.0f;
+        Ja = J + 6;
+    }
+    for (int i = 0; i < nJoints; ++i) {
+        float v = 0.0f;
+        if ((depMask >> i) & 1ull) {
+            const int jf = i + 1;
+            const float *Tm = T_mf + 12 * jf;
+            f3 ax; ax.x = jointAxis[3 * i]; ax.y = jointAxis[3 * i + 1]; ax.z = jointAxis[3 * i + 2];
+            if (jointType[i] == 0) {
+                const f3 rel = se3_apply_w(T_fm + 12 * jf, pm.x, pm.y, pm.z, pw);
+                const f3 dxa = cross(ax, rel);
+                const f3 dx = se3_rotate(Tm, dxa);
+                v = dot(grad, dx);
+            } else {
+                const f3 axm = se3_rotate(Tm, ax);
+                v = dot(grad, axm);
+            }
+        }
+        Ja[i] = v;
+    }
+}
+
+#endif  // __HIPCC__
+
+}  // namespace dartk

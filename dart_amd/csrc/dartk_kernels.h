@@ -1,0 +1,116 @@
+// dartk_kernels.h -- device building blocks shared by the term kernels and by the fused device-resident
+// Gauss-Newton loop (association, normal test, LDS staging, pose reductions).
+#pragma once
+
+#include "dartk_internal.h"
+#include "dartk_reduce.h"
+
+namespace dartk {
+
+static constexpr int NE_BLOCK = 128;   // lanes (= points per tile) of every normal-equation workgroup
+
+int ensure_partials(Workspace *w, size_t floats);
+int get_multi_args_buffer(void **d_ptr, size_t bytes);
+
+#ifdef __HIPCC__
+
+struct AssocResult {
+    int grid;      // associated SDF or -1
+    float err;     // signed distance in metres
+    f3 xm;         // point in the model frame
+    float w;       // homogeneous weight carried through the transforms
+};
+
+// Arg-min over the model's SDFs for one observed point (obsToMod.cu:45-76). The loop index is wave-uniform:
+// headers/transforms are scalar loads. Ties keep the lowest SDF index (strict <).
+__device__ __forceinline__ AssocResult associate_point(const ModelView &m, float4 xc, float distThr,
+                                                       float planeOffset, float pnx, float pny, float pnz) {
+    AssocResult r;
+    r.grid = -1; r.err = 1e20f; r.w = xc.w;
+    const float *__restrict__ T_mc = m.T_mc;
+    const float *__restrict__ T_fm = m.T_fm;
+    r.xm = se3_apply_w(T_mc, xc.x, xc.y, xc.z, xc.w);
+    f3 pn; pn.x = pnx; pn.y = pny; pn.z = pnz;
+    if (!(dot(r.xm, pn) >= planeOffset)) return r;
+    float best = 1e20f;
+    int grid = -1;
+    const int nSdfs = m.nSdfs;
+    for (int g = 0; g < nSdfs; ++g) {
+        const int f = m.sdfFrame[g];
+        const f3 xf = se3_apply_w(T_fm + 12 * f, r.xm.x, r.xm.y, r.xm.z, xc.w);
+        const SdfDev &s = m.sdfs[g];
+        const f3 xg = grid_coords(s, xf);
+        if (!in_bounds_grad_interp(s, xg)) continue;
+        const float d = grid_value(m.grids + s.dataOff, s.dimx, s.dimy, xg) * s.res;
+        if (d < best) { best = d; grid = g; }
+    }
+    if (best * best > distThr * distThr) grid = -1;   // obsToMod.cu:75 (1e20^2 = inf also lands here)
+    r.grid = grid; r.err = best;
+    return r;
+}
+
+// Normal-agreement gate of the single-model association (obsToMod.cu:78-96). Returns true when the point is
+// kept; nPred receives the predicted normal in the camera frame.
+__device__ __forceinline__ bool normal_test(const ModelView &m, const AssocResult &r, float4 nObs, float normThr,
+                                            float4 &nPred) {
+    const int f = m.sdfFrame[r.grid];
+    const SdfDev &s = m.sdfs[r.grid];
+    const float *__restrict__ T_fm = m.T_fm + 12 * f;
+    const f3 xf = se3_apply_w(T_fm, r.xm.x, r.xm.y, r.xm.z, r.w);
+    const f3 xg = grid_coords(s, xf);
+    const f3 gr = grid_gradient(m.grids + s.dataOff, s.dimx, s.dimy, xg);
+    float T_mc[12], T_fc[12], T_cf[12], T_f[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { T_mc[i] = m.T_mc[i]; T_f[i] = T_fm[i]; }
+    se3_mul(T_f, T_mc, T_fc);
+    se3_invert(T_fc, T_cf);
+    const float invLen = 1.0f / sqrtf(gr.x * gr.x + gr.y * gr.y + gr.z * gr.z + 0.0f * 0.0f);
+    const float gx = gr.x * invLen, gy = gr.y * invLen, gz = gr.z * invLen, gw = 0.0f * invLen;
+    const f3 n = se3_apply_w(T_cf, gx, gy, gz, gw);
+    nPred = make_float4(-1 * n.x, -1 * n.y, -1 * n.z, -1 * gw);
+    if (nObs.w > 0.0f) {
+        const float dp = nPred.x * nObs.x + nPred.y * nObs.y + nPred.z * nObs.z + nPred.w * 0.0f;
+        if (dp < normThr) return false;
+    }
+    return true;
+}
+
+// Copy the pose-dependent transforms and the SDF header table into LDS (once per workgroup); used where the
+// frame / SDF index differs per lane.
+__device__ __forceinline__ void stage_model(const ModelView &m, float *sT_fm, float *sT_mf, SdfDev *sSdf) {
+    const int n = 12 * m.nFrames;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { sT_fm[i] = m.T_fm[i]; sT_mf[i] = m.T_mf[i]; }
+    if (sSdf) {
+        const int nw = m.nSdfs * (int)(sizeof(SdfDev) / 4);
+        const int *src = reinterpret_cast<const int *>(m.sdfs);
+        int *dst = reinterpret_cast<int *>(sSdf);
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+// doPoseGradientReduction / doParamMapping (+ArticulationOnly), kernel_common.h:73-139.
+// off = 6 for full-pose systems, 0 for articulation-only ones.
+template <int RED>
+__device__ __forceinline__ void reduce_jacobian(float *J, const float *de, int off, int fullDims, int redDims,
+                                                const float *__restrict__ A, const int *__restrict__ mapping) {
+    const int nf = fullDims - 6, nr = redDims - 6;
+    for (int r = 0; r < off; ++r) J[r] = de[r];
+    if (RED == 1) {
+        for (int r = 0; r < nr; ++r) {
+            float acc = 0.0f;
+            for (int f = 0; f < nf; ++f) {
+                const float mult = A[r + f * nr];
+                if (mult == 0.f) continue;
+                acc += de[off + f] * mult;
+            }
+            J[off + r] = acc;
+        }
+    } else {
+        for (int r = 0; r < nr; ++r) J[off + r] = 0.0f;
+        for (int f = 0; f < nf; ++f) J[off + mapping[f]] += de[off + f];
+    }
+}
+
+#endif  // __HIPCC__
+
+}  // namespace dartk

@@ -1,0 +1,445 @@
+// dartk_model.hip -- library state, device buffers, model upload and on-device forward kinematics.
+// Replaces: util/mirrored_memory.h (device half), model/mirrored_model.cpp:8-225.
+#include "dartk_internal.h"
+#include "dartk_reduce.h"
+#include "dartk_kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+namespace dartk {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static Workspace g_ws[16];
+static bool g_ws_ready[16] = {false};
+
+int get_workspace(Workspace **out) {
+    int dev = 0;
+    DARTK_HIP(hipGetDevice(&dev));
+    DARTK_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+    if (!g_ws_ready[dev]) {
+        Workspace &w = g_ws[dev];
+        w.partialFloats = (size_t)kMaxPartialBlocks * 1024;   // grown on demand by ensure_partials
+        DARTK_HIP(hipMalloc((void **)&w.partials, w.partialFloats * sizeof(float)));
+        DARTK_HIP(hipMalloc((void **)&w.counters, 64 * sizeof(int)));
+        DARTK_HIP(hipMalloc((void **)&w.sysScratch, (size_t)8 * kMaxSys * sizeof(float)));
+        g_ws_ready[dev] = true;
+    }
+    *out = &g_ws[dev];
+    return DARTK_OK;
+}
+
+static void *g_multiArgs[16] = {nullptr};
+static size_t g_multiArgsBytes[16] = {0};
+int get_multi_args_buffer(void **d_ptr, size_t bytes) {
+    int dev = 0;
+    DARTK_HIP(hipGetDevice(&dev));
+    DARTK_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+    if (g_multiArgsBytes[dev] < bytes) {
+        if (g_multiArgs[dev]) DARTK_HIP(hipFree(g_multiArgs[dev]));
+        DARTK_HIP(hipMalloc(&g_multiArgs[dev], bytes));
+        g_multiArgsBytes[dev] = bytes;
+    }
+    *d_ptr = g_multiArgs[dev];
+    return DARTK_OK;
+}
+
+int ensure_partials(Workspace *w, size_t floats) {
+    if (floats <= w->partialFloats) return DARTK_OK;
+    DARTK_HIP(hipDeviceSynchronize());
+    DARTK_HIP(hipFree(w->partials));
+    w->partialFloats = floats;
+    DARTK_HIP(hipMalloc((void **)&w->partials, floats * sizeof(float)));
+    return DARTK_OK;
+}
+
+__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int nBlocks, int S, float *__restrict__ result,
+                                    int keep) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= S) return;
+    double s = 0.0;
+    if (keep) {
+        for (int b = 0; b < nBlocks; ++b) s += (double)slabs[(size_t)b * S + o];
+    }
+    result[o] = (float)s;
+}
+
+int launch_reduce_slabs(const float *slabs, int nBlocks, int S, float *result, int keep, hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((S + 127) / 128), dim3(128), 0, stream, slabs, nBlocks, S, result, keep);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
+// ---- forward kinematics on device -------------------------------------------------------------------
+// One wave; lane 0 walks the tree (nFrames <= 65, a few hundred flops): the point is to keep the pose on
+// the device so a Gauss-Newton iteration never round-trips to the host (reference: host FK + 2 blocking
+// H2D copies per setPose, mirrored_model.cpp:185-225).
+__device__ void dh_graspit(float theta, float d, float a, float alpha, float yrot, float *out) {
+    // RotY(y)*RotZ(theta)*Trans(0,0,d)*Trans(a,0,0)*RotX(alpha), left-associated (SE3.h:103-106)
+    const float cy = cosf(yrot), sy = sinf(yrot), ct = cosf(theta), st = sinf(theta), ca = cosf(alpha), sa = sinf(alpha);
+    float RY[12] = {cy, 0, sy, 0, 0, 1, 0, 0, -sy, 0, cy, 0};
+    float RZ[12] = {ct, -st, 0, 0, st, ct, 0, 0, 0, 0, 1, 0};
+    float TD[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, d};
+    float TA[12] = {1, 0, 0, a, 0, 1, 0, 0, 0, 0, 1, 0};
+    float RX[12] = {1, 0, 0, 0, 0, ca, -sa, 0, 0, sa, ca, 0};
+    float t[12];
+    se3_mul(RY, RZ, t);
+    se3_mul(t, TD, t);
+    se3_mul(t, TA, t);
+    se3_mul(t, RX, out);
+}
+
+__device__ void se3_exp(const float *p, float *out) {   // SE3Fromse3, SE3.h:147-180
+    const float wx = p[3], wy = p[4], wz = p[5];
+    const float theta = sqrtf(wx * wx + wy * wy + wz * wz);
+    if (theta == 0) {
+        out[0] = 1; out[1] = 0; out[2] = 0; out[3] = p[0];
+        out[4] = 0; out[5] = 1; out[6] = 0; out[7] = p[1];
+        out[8] = 0; out[9] = 0; out[10] = 1; out[11] = p[2];
+        return;
+    }
+    const float Va = (1 - cosf(theta)) / (theta * theta);
+    const float Vb = (theta - sinf(theta)) / (theta * theta * theta);
+    const float tx = (1 + Vb * (-wz * wz - wy * wy)) * p[0] + (Va * -wz + Vb * (wx * wy)) * p[1] + (Va * wy + Vb * (wx * wz)) * p[2];
+    const float ty = (Va * wz + Vb * (wx * wy)) * p[0] + (1 + Vb * (-wz * wz - wx * wx)) * p[1] + (Va * -wx + Vb * (wy * wz)) * p[2];
+    const float tz = (Va * -wy + Vb * (wx * wz)) * p[0] + (Va * wx + Vb * (wy * wz)) * p[1] + (1 + Vb * (-wy * wy - wx * wx)) * p[2];
+    const float a = sinf(theta) / theta;
+    const float b = (1 - cosf(theta)) / (theta * theta);
+    out[0] = 1 + b * (-wz * wz - wy * wy); out[1] = a * -wz + b * (wx * wy);      out[2] = a * wy + b * (wx * wz);        out[3] = tx;
+    out[4] = a * wz + b * (wx * wy);       out[5] = 1 + b * (-wz * wz - wx * wx); out[6] = a * -wx + b * (wy * wz);       out[7] = ty;
+    out[8] = a * -wy + b * (wx * wz);      out[9] = a * wx + b * (wy * wz);       out[10] = 1 + b * (-wy * wy - wx * wx); out[11] = tz;
+}
+
+// mode 0: setPose (GraspIt DH), 1: setArticulation (axis-angle)
+__device__ void fk_device(const ModelView &m, int mode) {
+    float *T_mf = m.T_mf, *T_fm = m.T_fm;
+    const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (int i = 0; i < 12; ++i) { T_mf[i] = I[i]; T_fm[i] = I[i]; }
+    for (int f = 1; f < m.nFrames; ++f) {
+        const int joint = f - 1;
+        const float p = fminf(fmaxf(m.limits[2 * joint], m.joints[joint]), m.limits[2 * joint + 1]);
+        m.joints[joint] = p;
+        const float ax = m.jointAxis[3 * joint], ay = m.jointAxis[3 * joint + 1], az = m.jointAxis[3 * joint + 2];
+        float D[12], T[12], P[12];
+        if (mode == 0) {
+            const float *dh = m.dh + 4 * joint;
+            if (m.jointType[joint] == 0) dh_graspit(dh[3] + p * az, dh[2], dh[0], dh[1] + p * ax, p * ay, D);
+            else                         dh_graspit(dh[3], dh[2] + p * az, dh[0] + p * ax, dh[1], p * ay, D);
+        } else {
+            float t6[6] = {0, 0, 0, 0, 0, 0};
+            if (m.jointType[joint] == 0) { t6[3] = p * ax; t6[4] = p * ay; t6[5] = p * az; }
+            else                         { t6[0] = p * ax; t6[1] = p * ay; t6[2] = p * az; }
+            se3_exp(t6, D);
+        }
+        for (int i = 0; i < 12; ++i) P[i] = m.T_pf[12 * joint + i];
+        se3_mul(P, D, T);
+        float parentT[12];
+        for (int i = 0; i < 12; ++i) parentT[i] = T_mf[12 * m.frameParent[f] + i];
+        float R[12], Rinv[12];
+        se3_mul(parentT, T, R);
+        se3_invert(R, Rinv);
+        for (int i = 0; i < 12; ++i) { T_mf[12 * f + i] = R[i]; T_fm[12 * f + i] = Rinv[i]; }
+    }
+}
+
+__global__ void fk_kernel(ModelView m, int mode) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (mode == 0) {
+            float inv[12];
+            se3_invert(m.T_mc, inv);
+            for (int i = 0; i < 12; ++i) m.T_cm[i] = inv[i];
+        }
+        fk_device(m, mode);
+    }
+}
+
+}  // namespace dartk
+
+using namespace dartk;
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char *dartk_last_error(void) { return g_err; }
+int dartk_version(void) { return 1; }
+
+int dartk_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) { set_error("no HIP device available (%s)", hipGetErrorString(e)); return DARTK_ERR_NO_DEVICE; }
+    DARTK_REQUIRE(device >= 0 && device < n, "device %d out of range (%d devices)", device, n);
+    DARTK_HIP(hipSetDevice(device));
+    Workspace *w;
+    return get_workspace(&w);
+}
+
+int dartk_buf_alloc(void **d_ptr, size_t bytes) {
+    DARTK_REQUIRE(d_ptr != nullptr, "dartk_buf_alloc: null out pointer");
+    DARTK_HIP(hipMalloc(d_ptr, bytes ? bytes : 4));
+    return DARTK_OK;
+}
+int dartk_buf_free(void *d_ptr) { DARTK_HIP(hipFree(d_ptr)); return DARTK_OK; }
+int dartk_buf_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream) {
+    DARTK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    DARTK_HIP(hipStreamSynchronize(as_stream(stream)));
+    return DARTK_OK;
+}
+int dartk_buf_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream) {
+    DARTK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    DARTK_HIP(hipStreamSynchronize(as_stream(stream)));
+    return DARTK_OK;
+}
+int dartk_buf_zero(void *d_ptr, size_t bytes, void *stream) {
+    DARTK_HIP(hipMemsetAsync(d_ptr, 0, bytes, as_stream(stream)));
+    return DARTK_OK;
+}
+int dartk_stream_sync(void *stream) { DARTK_HIP(hipStreamSynchronize(as_stream(stream))); return DARTK_OK; }
+
+static float next_above(double v) {   // smallest float strictly greater than v
+    float f = (float)v;
+    while ((double)f <= v) f = nextafterf(f, INFINITY);
+    while ((double)nextafterf(f, -INFINITY) > v) f = nextafterf(f, -INFINITY);
+    return f;
+}
+static float next_below(double v) {   // largest float strictly less than v
+    float f = (float)v;
+    while ((double)f >= v) f = nextafterf(f, -INFINITY);
+    while ((double)nextafterf(f, INFINITY) < v) f = nextafterf(f, INFINITY);
+    return f;
+}
+static void fill_bounds(SdfDev &s) {
+    s.lo25 = next_above(2.50001);
+    s.hi25x = next_below((double)(unsigned)s.dimx - 2.50001);
+    s.hi25y = next_below((double)(unsigned)s.dimy - 2.50001);
+    s.hi25z = next_below((double)(unsigned)s.dimz - 2.50001);
+    s.lo05 = next_above(0.50001);
+    s.hi05x = next_below((double)(unsigned)s.dimx - 0.50001);
+    s.hi05y = next_below((double)(unsigned)s.dimy - 0.50001);
+    s.hi05z = next_below((double)(unsigned)s.dimz - 0.50001);
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int dartk_model_create(const dartk_model_desc *d, dartk_model_t *out) {
+    DARTK_REQUIRE(d && out, "dartk_model_create: null argument");
+    DARTK_REQUIRE(d->n_frames >= 1 && d->n_joints == d->n_frames - 1,
+                  "model must have n_joints == n_frames-1 (joint i drives frame i+1, mirrored_model.h:38); got %d/%d",
+                  d->n_joints, d->n_frames);
+    DARTK_REQUIRE(d->n_joints <= DARTK_MAX_JOINTS, "at most %d joints supported, got %d", DARTK_MAX_JOINTS, d->n_joints);
+    DARTK_REQUIRE(d->n_sdfs >= 1 && d->n_sdfs <= 65535, "n_sdfs %d out of range", d->n_sdfs);
+    for (int s = 0; s < d->n_sdfs; ++s) {
+        DARTK_REQUIRE(d->sdf_frame[s] >= 0 && d->sdf_frame[s] < d->n_frames, "sdf %d: frame %d out of range", s, d->sdf_frame[s]);
+        DARTK_REQUIRE(d->sdf_dim[3 * s] >= 6 && d->sdf_dim[3 * s + 1] >= 6 && d->sdf_dim[3 * s + 2] >= 6,
+                      "sdf %d: every dimension must be >= 6 voxels", s);
+        DARTK_REQUIRE(d->sdf_resolution[s] > 0, "sdf %d: resolution must be positive", s);
+    }
+    for (int f = 1; f < d->n_frames; ++f)
+        DARTK_REQUIRE(d->frame_parent[f] >= 0 && d->frame_parent[f] < f, "frame %d: parent %d must precede it", f, d->frame_parent[f]);
+
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+
+    const int nF = d->n_frames, nJ = d->n_joints, nS = d->n_sdfs;
+    const int nJa = nJ > 0 ? nJ : 1;
+    // arena layout
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_sdfs = take(sizeof(SdfDev) * nS);
+    const size_t o_sdfFrame = take(sizeof(int) * nS);
+    const size_t o_dep = take(sizeof(unsigned long long) * nF);
+    const size_t o_jt = take(sizeof(int) * nJa);
+    const size_t o_ax = take(sizeof(float) * 3 * nJa);
+    const size_t o_tpf = take(sizeof(float) * 12 * nJa);
+    const size_t o_dh = take(sizeof(float) * 4 * nJa);
+    const size_t o_lim = take(sizeof(float) * 2 * nJa);
+    const size_t o_par = take(sizeof(int) * nF);
+    const size_t staticBytes = off;
+    const size_t o_Tmc = take(sizeof(float) * 12);
+    const size_t o_Tcm = take(sizeof(float) * 12);
+    const size_t o_Tmf = take(sizeof(float) * 12 * nF);
+    const size_t o_Tfm = take(sizeof(float) * 12 * nF);
+    const size_t o_joints = take(sizeof(float) * nJa);
+    const size_t o_grids = off;
+
+    std::vector<SdfDev> sdfs(nS);
+    size_t gridFloats = 0;
+    for (int s = 0; s < nS; ++s) {
+        SdfDev &g = sdfs[s];
+        g.dimx = d->sdf_dim[3 * s]; g.dimy = d->sdf_dim[3 * s + 1]; g.dimz = d->sdf_dim[3 * s + 2];
+        g.ox = d->sdf_offset[3 * s]; g.oy = d->sdf_offset[3 * s + 1]; g.oz = d->sdf_offset[3 * s + 2];
+        g.res = d->sdf_resolution[s];
+        g.dataOff = (int)gridFloats;
+        fill_bounds(g);
+        gridFloats = align_up(gridFloats + (size_t)g.dimx * g.dimy * g.dimz, 64);
+        DARTK_REQUIRE(gridFloats < (size_t)1 << 31, "SDF arena exceeds 2^31 voxels");
+    }
+    off = align_up(o_grids + gridFloats * sizeof(float), 256);
+    const size_t o_obs = off;
+    size_t obsVoxels = (size_t)d->obs_sdf_dim[0] * d->obs_sdf_dim[1] * d->obs_sdf_dim[2];
+    off = align_up(off + (obsVoxels ? obsVoxels : 1) * sizeof(float), 256);
+    const size_t total = off;
+
+    Model *m = new Model();
+    memset(m, 0, sizeof(Model));
+    DARTK_HIP(hipGetDevice(&m->device));
+    DARTK_HIP(hipMalloc(&m->arena, total));
+    m->arenaBytes = total;
+    DARTK_HIP(hipHostMalloc((void **)&m->h_pin, sizeof(float) * (12 + 24 * nF + nJa), hipHostMallocDefault));
+
+    // build the static + grid parts on the host, then one H2D copy
+    std::vector<unsigned char> h(total, 0);
+    memcpy(h.data() + o_sdfs, sdfs.data(), sizeof(SdfDev) * nS);
+    memcpy(h.data() + o_sdfFrame, d->sdf_frame, sizeof(int) * nS);
+    unsigned long long *dep = (unsigned long long *)(h.data() + o_dep);
+    for (int f = 0; f < nF; ++f) {
+        unsigned long long bits = 0;
+        for (int j = 0; j < nJ; ++j) if (d->dependencies[f * nJ + j]) bits |= (1ull << j);
+        dep[f] = bits;
+    }
+    if (nJ > 0) {
+        memcpy(h.data() + o_jt, d->joint_type, sizeof(int) * nJ);
+        memcpy(h.data() + o_ax, d->joint_axis, sizeof(float) * 3 * nJ);
+        memcpy(h.data() + o_tpf, d->T_pf, sizeof(float) * 12 * nJ);
+        memcpy(h.data() + o_dh, d->dh, sizeof(float) * 4 * nJ);
+        memcpy(h.data() + o_lim, d->joint_limits, sizeof(float) * 2 * nJ);
+    }
+    memcpy(h.data() + o_par, d->frame_parent, sizeof(int) * nF);
+    {
+        const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        memcpy(h.data() + o_Tmc, I, sizeof(I));
+        memcpy(h.data() + o_Tcm, I, sizeof(I));
+        for (int f = 0; f < nF; ++f) {
+            memcpy(h.data() + o_Tmf + sizeof(I) * f, I, sizeof(I));
+            memcpy(h.data() + o_Tfm + sizeof(I) * f, I, sizeof(I));
+        }
+    }
+    for (int s = 0; s < nS; ++s) {
+        const size_t n = (size_t)sdfs[s].dimx * sdfs[s].dimy * sdfs[s].dimz;
+        memcpy(h.data() + o_grids + sizeof(float) * sdfs[s].dataOff, d->sdf_data[s], n * sizeof(float));
+    }
+    DARTK_HIP(hipMemcpy(m->arena, h.data(), total, hipMemcpyHostToDevice));
+    (void)staticBytes;
+
+    unsigned char *base = (unsigned char *)m->arena;
+    ModelView &v = m->v;
+    v.nFrames = nF; v.nJoints = nJ; v.nSdfs = nS; v.modelId = d->model_id;
+    v.sdfs = (const SdfDev *)(base + o_sdfs);
+    v.sdfFrame = (const int *)(base + o_sdfFrame);
+    v.depMask = (const unsigned long long *)(base + o_dep);
+    v.jointType = (const int *)(base + o_jt);
+    v.jointAxis = (const float *)(base + o_ax);
+    v.T_pf = (const float *)(base + o_tpf);
+    v.dh = (const float *)(base + o_dh);
+    v.limits = (const float *)(base + o_lim);
+    v.frameParent = (const int *)(base + o_par);
+    v.grids = (const float *)(base + o_grids);
+    v.T_mc = (float *)(base + o_Tmc);
+    v.T_cm = (float *)(base + o_Tcm);
+    v.T_mf = (float *)(base + o_Tmf);
+    v.T_fm = (float *)(base + o_Tfm);
+    v.joints = (float *)(base + o_joints);
+    memset(&v.obs, 0, sizeof(SdfDev));
+    v.obs.dimx = d->obs_sdf_dim[0]; v.obs.dimy = d->obs_sdf_dim[1]; v.obs.dimz = d->obs_sdf_dim[2];
+    v.obs.ox = d->obs_sdf_offset[0]; v.obs.oy = d->obs_sdf_offset[1]; v.obs.oz = d->obs_sdf_offset[2];
+    v.obs.res = d->obs_sdf_resolution;
+    if (obsVoxels) fill_bounds(v.obs);
+    v.obsData = (float *)(base + o_obs);
+    m->obsVoxels = obsVoxels;
+    m->dtTmp = nullptr;
+    if (obsVoxels) DARTK_HIP(hipMalloc((void **)&m->dtTmp, obsVoxels * sizeof(float)));
+    *out = reinterpret_cast<dartk_model_t>(m);
+    return DARTK_OK;
+}
+
+int dartk_model_destroy(dartk_model_t h) {
+    Model *m = reinterpret_cast<Model *>(h);
+    if (!m) return DARTK_OK;
+    if (m->dtTmp) (void)hipFree(m->dtTmp);
+    (void)hipHostFree(m->h_pin);
+    (void)hipFree(m->arena);
+    delete m;
+    return DARTK_OK;
+}
+
+static int upload_pose_and_fk(Model *m, const float *h_T_mc, const float *h_joints, int mode, void *stream) {
+    hipStream_t st = as_stream(stream);
+    const int nJ = m->v.nJoints;
+    // pinned staging is reused: wait for any previous async copy from it before overwriting
+    DARTK_HIP(hipStreamSynchronize(st));
+    if (h_T_mc) {
+        memcpy(m->h_pin, h_T_mc, 12 * sizeof(float));
+        DARTK_HIP(hipMemcpyAsync(m->v.T_mc, m->h_pin, 12 * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    if (nJ > 0) {
+        DARTK_REQUIRE(h_joints != nullptr, "joint array required for an articulated model");
+        memcpy(m->h_pin + 12, h_joints, nJ * sizeof(float));
+        DARTK_HIP(hipMemcpyAsync(m->v.joints, m->h_pin + 12, nJ * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(fk_kernel, dim3(1), dim3(64), 0, st, m->v, mode);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
+int dartk_model_set_pose(dartk_model_t h, const float *h_T_mc, const float *h_joints, void *stream) {
+    Model *m = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(m && h_T_mc, "dartk_model_set_pose: null argument");
+    return upload_pose_and_fk(m, h_T_mc, h_joints, 0, stream);
+}
+
+int dartk_model_set_articulation(dartk_model_t h, const float *h_joints, void *stream) {
+    Model *m = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(m, "dartk_model_set_articulation: null model");
+    return upload_pose_and_fk(m, nullptr, h_joints, 1, stream);
+}
+
+int dartk_model_set_transforms(dartk_model_t h, const float *h_T_mc, const float *h_T_mf, const float *h_T_fm, void *stream) {
+    Model *m = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(m && h_T_mc && h_T_mf && h_T_fm, "dartk_model_set_transforms: null argument");
+    hipStream_t st = as_stream(stream);
+    const int nF = m->v.nFrames;
+    float T_cm[12];
+    {   // SE3Invert on the host (pose.h keeps both directions)
+        const float *A = h_T_mc;
+        T_cm[0] = A[0]; T_cm[1] = A[4]; T_cm[2] = A[8];   T_cm[3]  = -(A[0] * A[3] + A[4] * A[7] + A[8] * A[11]);
+        T_cm[4] = A[1]; T_cm[5] = A[5]; T_cm[6] = A[9];   T_cm[7]  = -(A[1] * A[3] + A[5] * A[7] + A[9] * A[11]);
+        T_cm[8] = A[2]; T_cm[9] = A[6]; T_cm[10] = A[10]; T_cm[11] = -(A[2] * A[3] + A[6] * A[7] + A[10] * A[11]);
+    }
+    DARTK_HIP(hipMemcpyAsync(m->v.T_mc, h_T_mc, 12 * sizeof(float), hipMemcpyHostToDevice, st));
+    DARTK_HIP(hipMemcpyAsync(m->v.T_cm, T_cm, 12 * sizeof(float), hipMemcpyHostToDevice, st));
+    DARTK_HIP(hipMemcpyAsync(m->v.T_mf, h_T_mf, 12 * nF * sizeof(float), hipMemcpyHostToDevice, st));
+    DARTK_HIP(hipMemcpyAsync(m->v.T_fm, h_T_fm, 12 * nF * sizeof(float), hipMemcpyHostToDevice, st));
+    DARTK_HIP(hipStreamSynchronize(st));
+    return DARTK_OK;
+}
+
+int dartk_model_get_transforms(dartk_model_t h, float *h_T_mc, float *h_T_mf, float *h_T_fm, float *h_joints) {
+    Model *m = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(m, "dartk_model_get_transforms: null model");
+    DARTK_HIP(hipDeviceSynchronize());
+    const int nF = m->v.nFrames;
+    if (h_T_mc) DARTK_HIP(hipMemcpy(h_T_mc, m->v.T_mc, 12 * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_T_mf) DARTK_HIP(hipMemcpy(h_T_mf, m->v.T_mf, 12 * nF * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_T_fm) DARTK_HIP(hipMemcpy(h_T_fm, m->v.T_fm, 12 * nF * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_joints && m->v.nJoints) DARTK_HIP(hipMemcpy(h_joints, m->v.joints, m->v.nJoints * sizeof(float), hipMemcpyDeviceToHost));
+    return DARTK_OK;
+}
+
+int dartk_model_num_sdfs(dartk_model_t h) { return h ? reinterpret_cast<Model *>(h)->v.nSdfs : 0; }
+int dartk_model_dims(dartk_model_t h) { return h ? 6 + reinterpret_cast<Model *>(h)->v.nJoints : 0; }
+float *dartk_model_obs_sdf_data(dartk_model_t h) { return h ? reinterpret_cast<Model *>(h)->v.obsData : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,353 @@
+// dartk_obs2mod.hip -- observation-to-model data association and its normal equations.
+// Replaces: optimization/kernels/obsToMod.cu (kernels :12-501, host wrappers :504-817).
+#include "dartk_internal.h"
+#include "dartk_reduce.h"
+#include "dartk_kernels.h"
+
+namespace dartk {
+
+// -----------------------------------------------------------------------------------------------------
+// association, single model (obsToMod.cu:12-114). One lane per pixel, 256-lane workgroups over the
+// row-major map: each wave reads 64 consecutive float4 = 1 KiB per load instruction. The loop over SDFs is
+// wave-uniform, so SDF headers and frame transforms come through the scalar cache. The append is one
+// atomic per wave (ballot + popcount), not one per pixel.
+// -----------------------------------------------------------------------------------------------------
+template <bool DBG>
+__global__ void __launch_bounds__(256)
+assoc_single_kernel(const float4 *__restrict__ vert, const float4 *__restrict__ norm, int nPix, ModelView m,
+                    float distThr, float normThr, float planeOffset, float pnx, float pny, float pnz,
+                    int *__restrict__ lastElement, dartk_da_point *__restrict__ pts, int *__restrict__ dbgDA,
+                    float *__restrict__ dbgErr, float4 *__restrict__ dbgNorm) {
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    bool emit = false;
+    int grid = -1;
+    float sdfError = 1e20f;
+    if (index < nPix) {
+        if (DBG) {
+            if (dbgDA) dbgDA[index] = -1;
+            if (dbgErr) dbgErr[index] = __builtin_nanf("");
+            if (dbgNorm) dbgNorm[index] = make_float4(0, 0, 0, 0);
+        }
+        const float4 xc = vert[index];
+        if (xc.w > 0) {
+            const AssocResult r = associate_point(m, xc, distThr, planeOffset, pnx, pny, pnz);
+            grid = r.grid; sdfError = r.err;
+            if (r.grid >= 0) {
+                // normal test (obsToMod.cu:78-96)
+                float4 nPred;
+                emit = normal_test(m, r, norm[index], normThr, nPred);
+                if (DBG && dbgNorm) dbgNorm[index] = nPred;
+                if (emit && DBG) {
+                    if (dbgDA) dbgDA[index] = grid;
+                    if (dbgErr) dbgErr[index] = sdfError;
+                }
+            }
+        }
+    }
+    const unsigned long long mask = __ballot(emit);
+    if (mask) {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(lastElement, __popcll(mask));
+        base = __shfl(base, 0);
+        if (emit) {
+            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            dartk_da_point p;
+            p.index = index; p.dataAssociation = grid; p.error = sdfError;
+            pts[base + __popcll(mask & lt)] = p;
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// association, multi model (obsToMod.cu:116-244): threshold inside the arg-min, no normal test.
+// -----------------------------------------------------------------------------------------------------
+struct MultiArgs {
+    int nModels;
+    ModelView m[DARTK_MAX_MODELS];
+    float distThr[DARTK_MAX_MODELS];
+    float planeOffset[DARTK_MAX_MODELS];
+    float pn[DARTK_MAX_MODELS][3];
+    dartk_da_point *pts[DARTK_MAX_MODELS];
+};
+
+template <bool DBG>
+__global__ void __launch_bounds__(256)
+assoc_multi_kernel(const float4 *__restrict__ vert, int nPix, const MultiArgs *__restrict__ args,
+                   int *__restrict__ lastElement, int *__restrict__ dbgDA, float *__restrict__ dbgErr) {
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    int aModel = -1, aGrid = -1;
+    float sdfError = 1e20f;
+    if (index < nPix) {
+        if (DBG) {
+            if (dbgDA) dbgDA[index] = -1;
+            if (dbgErr) dbgErr[index] = __builtin_nanf("");
+        }
+        const float4 xc = vert[index];
+        if (xc.w > 0) {
+            const int nModels = args->nModels;
+            for (int mi = 0; mi < nModels; ++mi) {
+                const ModelView &m = args->m[mi];
+                const float *__restrict__ T_mc = m.T_mc;
+                const f3 xm = se3_apply_w(T_mc, xc.x, xc.y, xc.z, xc.w);
+                f3 pn; pn.x = args->pn[mi][0]; pn.y = args->pn[mi][1]; pn.z = args->pn[mi][2];
+                if (!(dot(xm, pn) >= args->planeOffset[mi])) continue;
+                const float thr = args->distThr[mi];
+                const float *__restrict__ T_fm = m.T_fm;
+                for (int g = 0; g < m.nSdfs; ++g) {
+                    const int f = m.sdfFrame[g];
+                    const f3 xf = se3_apply_w(T_fm + 12 * f, xm.x, xm.y, xm.z, xc.w);
+                    const SdfDev &s = m.sdfs[g];
+                    const f3 xg = grid_coords(s, xf);
+                    if (!in_bounds_grad_interp(s, xg)) continue;
+                    const float d = grid_value(m.grids + s.dataOff, s.dimx, s.dimy, xg) * s.res;
+                    if (d < sdfError) {
+                        if (d * d < thr * thr) { sdfError = d; aGrid = g; aModel = mi; }
+                    }
+                }
+            }
+            if (DBG && aModel != -1) {
+                if (dbgDA) dbgDA[index] = ((aModel << 16) | aGrid);
+                if (dbgErr) dbgErr[index] = sdfError;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    const int nModels = args->nModels;
+    for (int mi = 0; mi < nModels; ++mi) {     // per-model wave-aggregated append
+        const bool mine = (aModel == mi);
+        const unsigned long long mask = __ballot(mine);
+        if (!mask) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&lastElement[mi], __popcll(mask));
+        base = __shfl(base, 0);
+        if (mine) {
+            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            dartk_da_point p;
+            p.index = index; p.dataAssociation = aGrid; p.error = sdfError;
+            args->pts[mi][base + __popcll(mask & lt)] = p;
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// normal equations over the associated-point list (obsToMod.cu:246-501)
+// RED: 0 full pose, 1 linear reduction, 2 parameter map.
+// LDS: [T_fm | T_mf] (24*nFrames) | SdfDev table (16*nSdfs words) | scratch J (NE_BLOCK*fullDims, reduced only)
+//      | rows (NE_BLOCK*ld) | wave counters
+// -----------------------------------------------------------------------------------------------------
+template <int PPT, int RED>
+__global__ void __launch_bounds__(NE_BLOCK)
+ne_obs2mod_kernel(const dartk_da_point *__restrict__ pts, const float4 *__restrict__ vert, int nPoints, ModelView m,
+                  float huberDelta, int redDims, const float *__restrict__ dtheta_dalpha,
+                  const int *__restrict__ mapping, float *__restrict__ slabs) {
+    extern __shared__ float lds[];
+    const int fullDims = 6 + m.nJoints;
+    const int d = RED ? redDims : fullDims;
+    const bool drop = (RED != 0);
+    const int ld = row_len(d, drop);
+    float *sT_fm = lds;
+    float *sT_mf = sT_fm + 12 * m.nFrames;
+    SdfDev *sSdf = reinterpret_cast<SdfDev *>(sT_mf + 12 * m.nFrames);
+    float *sFull = reinterpret_cast<float *>(sSdf + m.nSdfs);          // [NE_BLOCK][fullDims|1] when RED
+    const int fullLd = fullDims | 1;
+    float *rows = sFull + (RED ? NE_BLOCK * fullLd : 0);
+    stage_model(m, sT_fm, sT_mf, sSdf);
+    float T_mc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T_mc[i] = m.T_mc[i];
+    __syncthreads();
+
+    PairAcc<NE_BLOCK, PPT> acc;
+    acc.init(d, drop);
+
+    const int nTiles = (nPoints + NE_BLOCK - 1) / NE_BLOCK;
+    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        const int k = tile * NE_BLOCK + threadIdx.x;
+        float *row = rows + threadIdx.x * ld;
+        if (k < nPoints) {
+            const dartk_da_point pt = pts[k];
+            const float4 xc = vert[pt.index];
+            const f3 xm = se3_apply_w(T_mc, xc.x, xc.y, xc.z, xc.w);
+            const int g = pt.dataAssociation;
+            const int frame = m.sdfFrame[g];
+            const f3 xf = se3_apply_w(sT_fm + 12 * frame, xm.x, xm.y, xm.z, xc.w);
+            const SdfDev s = sSdf[g];
+            const f3 xg = grid_coords(s, xf);
+            const f3 gf = grid_gradient(m.grids + s.dataOff, s.dimx, s.dimy, xg);
+            const f3 gm = se3_rotate(sT_mf + 12 * frame, gf);
+            float *Jfull = RED ? (sFull + threadIdx.x * fullLd) : row;
+            error_jacobian<false>(Jfull, xm, xc.w, m.depMask[frame], gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
+            if (RED) reduce_jacobian<RED>(row, Jfull, 6, fullDims, redDims, dtheta_dalpha, mapping);
+            const float err = pt.error;
+            const bool inlier = fabsf(err) < huberDelta;
+            float r, E;
+            if (inlier) { r = -err; E = (float)(0.5 * (double)r * (double)r); }
+            else {
+                const float v = (err < 0) ? -huberDelta : huberDelta;
+                r = -v;
+                E = (float)((double)huberDelta * ((double)fabsf(err) - 0.5 * (double)huberDelta));
+            }
+            row[d] = r; row[d + 1] = E; row[d + 2] = 1.0f;
+            if (drop) {
+                for (int i = 0; i < d; ++i) row[d + 3 + i] = inlier ? row[i] : 0.0f;
+            }
+        }
+        __syncthreads();
+        const int n = min(NE_BLOCK, nPoints - tile * NE_BLOCK);
+        acc.accumulate(rows, ld, n);
+        __syncthreads();
+    }
+    acc.store(slabs + (size_t)blockIdx.x * sys_size(d), sys_size(d));
+}
+
+size_t ne_obs2mod_lds_bytes(const ModelView &m, int d, int red) {
+    const int fullDims = 6 + m.nJoints;
+    size_t words = 24 * (size_t)m.nFrames + 16 * (size_t)m.nSdfs + (size_t)NE_BLOCK * row_len(d, red != 0);
+    if (red) words += (size_t)NE_BLOCK * (fullDims | 1);
+    return words * sizeof(float);
+}
+
+template <int RED>
+static int launch_ne_obs2mod(int fullDims, int redDims, const float *d_vert, Model *mod, float huberDelta,
+                             const dartk_da_point *d_pts, int nElements, const float *d_A, const int *d_map,
+                             float *d_result, hipStream_t st) {
+    const ModelView &m = mod->v;
+    const int d = RED ? redDims : fullDims;
+    DARTK_REQUIRE(fullDims == 6 + m.nJoints, "dims %d does not match the model's 6+%d", fullDims, m.nJoints);
+    DARTK_REQUIRE(d >= 6 && d <= kMaxDims, "system dimension %d out of range [6,%d]", d, kMaxDims);
+    DARTK_REQUIRE(nElements >= 0, "negative element count");
+    const int S = sys_size(d);
+    if (nElements <= 10) {    // obsToMod.cu:644-646: memset only
+        DARTK_HIP(hipMemsetAsync(d_result, 0, S * sizeof(float), st));
+        return DARTK_OK;
+    }
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    const int nTiles = (nElements + NE_BLOCK - 1) / NE_BLOCK;
+    const int nBlocks = nTiles < kMaxPartialBlocks ? nTiles : kMaxPartialBlocks;
+    rc = ensure_partials(ws, (size_t)nBlocks * S);
+    if (rc) return rc;
+    const size_t ldsBytes = ne_obs2mod_lds_bytes(m, d, RED);
+    DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
+    const float4 *vert = reinterpret_cast<const float4 *>(d_vert);
+#define DARTK_LAUNCH_NE(PPT_)                                                                                   \
+    do {                                                                                                        \
+        auto kfn = ne_obs2mod_kernel<PPT_, RED>;                                                                \
+        if (ldsBytes > 64 * 1024)                                                                               \
+            DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, nElements, m,         \
+                           huberDelta, redDims, d_A, d_map, ws->partials);                                      \
+    } while (0)
+    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_NE(3);
+    else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_NE(6);
+    else DARTK_LAUNCH_NE(20);
+#undef DARTK_LAUNCH_NE
+    DARTK_HIP(hipGetLastError());
+    return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
+}
+
+}  // namespace dartk
+
+using namespace dartk;
+
+extern "C" {
+
+int dartk_assoc_single(const float *d_vert, const float *d_norm, int width, int height, dartk_model_t h,
+                       float distThreshold, float normThreshold, float planeOffset, const float *pn,
+                       dartk_da_point *d_pts, int32_t *d_last, int32_t *h_last, int32_t *d_dbgDA, float *d_dbgErr,
+                       float *d_dbgNorm, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_vert && d_norm && d_pts && d_last && pn, "dartk_assoc_single: null argument");
+    DARTK_REQUIRE(width > 0 && height > 0 && (long long)width * height < (1ll << 31), "bad map size %dx%d", width, height);
+    hipStream_t st = as_stream(stream);
+    const int nPix = width * height;
+    DARTK_HIP(hipMemsetAsync(d_last, 0, sizeof(int), st));
+    const dim3 grid((nPix + 255) / 256), block(256);
+    const bool dbg = d_dbgDA || d_dbgErr || d_dbgNorm;
+    if (dbg)
+        hipLaunchKernelGGL(assoc_single_kernel<true>, grid, block, 0, st, (const float4 *)d_vert, (const float4 *)d_norm,
+                           nPix, mod->v, distThreshold, normThreshold, planeOffset, pn[0], pn[1], pn[2], d_last, d_pts,
+                           d_dbgDA, d_dbgErr, (float4 *)d_dbgNorm);
+    else
+        hipLaunchKernelGGL(assoc_single_kernel<false>, grid, block, 0, st, (const float4 *)d_vert, (const float4 *)d_norm,
+                           nPix, mod->v, distThreshold, normThreshold, planeOffset, pn[0], pn[1], pn[2], d_last, d_pts,
+                           nullptr, nullptr, nullptr);
+    DARTK_HIP(hipGetLastError());
+    if (h_last) {
+        DARTK_HIP(hipMemcpyAsync(h_last, d_last, sizeof(int), hipMemcpyDeviceToHost, st));
+        DARTK_HIP(hipStreamSynchronize(st));
+    }
+    return DARTK_OK;
+}
+
+int dartk_assoc_multi(const float *d_vert, const float *d_norm, int width, int height, int nModels,
+                      const dartk_model_t *models, const float *h_distThresholds, const float *h_planeOffsets,
+                      const float *h_planeNormals3, dartk_da_point *const *h_pts_table, int32_t *d_last,
+                      int32_t *d_dbgDA, float *d_dbgErr, void *stream) {
+    (void)d_norm;
+    DARTK_REQUIRE(d_vert && models && h_distThresholds && h_planeOffsets && h_planeNormals3 && h_pts_table && d_last,
+                  "dartk_assoc_multi: null argument");
+    DARTK_REQUIRE(nModels >= 1 && nModels <= DARTK_MAX_MODELS, "nModels %d out of range [1,%d]", nModels, DARTK_MAX_MODELS);
+    DARTK_REQUIRE(width > 0 && height > 0 && (long long)width * height < (1ll << 31), "bad map size %dx%d", width, height);
+    hipStream_t st = as_stream(stream);
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    static thread_local MultiArgs hargs;
+    hargs.nModels = nModels;
+    for (int i = 0; i < nModels; ++i) {
+        Model *mod = reinterpret_cast<Model *>(models[i]);
+        DARTK_REQUIRE(mod && h_pts_table[i], "dartk_assoc_multi: null model or point buffer %d", i);
+        hargs.m[i] = mod->v;
+        hargs.distThr[i] = h_distThresholds[i];
+        hargs.planeOffset[i] = h_planeOffsets[i];
+        for (int k = 0; k < 3; ++k) hargs.pn[i][k] = h_planeNormals3[3 * i + k];
+        hargs.pts[i] = h_pts_table[i];
+    }
+    MultiArgs *d_args = nullptr;
+    rc = get_multi_args_buffer((void **)&d_args, sizeof(MultiArgs));
+    if (rc) return rc;
+    DARTK_HIP(hipMemcpyAsync(d_args, &hargs, sizeof(MultiArgs), hipMemcpyHostToDevice, st));
+    DARTK_HIP(hipStreamSynchronize(st));   // hargs is reused by the next call
+    DARTK_HIP(hipMemsetAsync(d_last, 0, nModels * sizeof(int), st));
+    const int nPix = width * height;
+    const dim3 grid((nPix + 255) / 256), block(256);
+    if (d_dbgDA || d_dbgErr)
+        hipLaunchKernelGGL(assoc_multi_kernel<true>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, d_dbgDA, d_dbgErr);
+    else
+        hipLaunchKernelGGL(assoc_multi_kernel<false>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, nullptr, nullptr);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
+int dartk_ne_obs2mod(int dims, const float *d_vert, int width, int height, dartk_model_t h, float huberDelta,
+                     const dartk_da_point *d_pts, int nElements, float *d_result, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_vert && d_pts && d_result, "dartk_ne_obs2mod: null argument");
+    DARTK_REQUIRE(nElements <= width * height, "nElements %d exceeds the map size", nElements);
+    return launch_ne_obs2mod<0>(dims, dims, d_vert, mod, huberDelta, d_pts, nElements, nullptr, nullptr, d_result, as_stream(stream));
+}
+
+int dartk_ne_obs2mod_reduced(int dims, int redDims, const float *d_A, const float *d_vert, int width, int height,
+                             dartk_model_t h, float huberDelta, const dartk_da_point *d_pts, int nElements,
+                             float *d_result, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_vert && d_pts && d_result && d_A, "dartk_ne_obs2mod_reduced: null argument");
+    DARTK_REQUIRE(nElements <= width * height, "nElements %d exceeds the map size", nElements);
+    DARTK_REQUIRE(redDims >= 6 && redDims <= dims, "redDims %d must be in [6,%d]", redDims, dims);
+    return launch_ne_obs2mod<1>(dims, redDims, d_vert, mod, huberDelta, d_pts, nElements, d_A, nullptr, d_result, as_stream(stream));
+}
+
+int dartk_ne_obs2mod_parammap(int dims, int redDims, const int32_t *d_map, const float *d_vert, int width, int height,
+                              dartk_model_t h, float huberDelta, const dartk_da_point *d_pts, int nElements,
+                              float *d_result, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_vert && d_pts && d_result && d_map, "dartk_ne_obs2mod_parammap: null argument");
+    DARTK_REQUIRE(nElements <= width * height, "nElements %d exceeds the map size", nElements);
+    DARTK_REQUIRE(redDims >= 6 && redDims <= dims, "redDims %d must be in [6,%d]", redDims, dims);
+    return launch_ne_obs2mod<2>(dims, redDims, d_vert, mod, huberDelta, d_pts, nElements, nullptr, d_map, d_result, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+"""Python host layer over the C ABI: device-resident models and the per-term entry points.
+
+torch is used only for device memory and streams (tensors own the HBM buffers; their data_ptr() is what crosses
+the C ABI). Names follow the reference: MirroredModel -> DeviceModel, the free functions of
+optimization/kernels/*.h keep their names in snake case.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._abi import check, lib
+
+F = np.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def init(device=0):
+    check(lib().dartk_init(int(device)))
+    torch.cuda.set_device(device)
+
+
+class DeviceModel:
+    """MirroredModel (src/model/mirrored_model.h): SDFs, kinematic tables and the current pose, in HBM."""
+
+    _next_id = 0
+
+    def __init__(self, host_model, model_id=None, obs_layout=None):
+        self.host = host_model
+        if model_id is None:                     # static nextModelID counter, mirrored_model.cpp:14-20
+            model_id = DeviceModel._next_id
+            DeviceModel._next_id += 1
+        self.model_id = model_id
+        self.obs_layout = obs_layout
+        desc, keep = _abi.fill_model_desc(_abi.ModelDesc, host_model, model_id, obs_layout)
+        h = C.c_void_p()
+        check(lib().dartk_model_create(C.byref(desc), C.byref(h)))
+        self.handle = h
+        self.n_frames, self.n_joints, self.n_sdfs = host_model.n_frames, host_model.n_joints, len(host_model.sdfs)
+        self.dims = 6 + self.n_joints
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                lib().dartk_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def set_pose(self, T_mc, joints):
+        T = np.ascontiguousarray(T_mc, dtype=F).reshape(12)
+        j = np.ascontiguousarray(joints, dtype=F).reshape(-1) if self.n_joints else np.zeros(1, dtype=F)
+        check(lib().dartk_model_set_pose(self.handle, _abi.fptr(T), _abi.fptr(j), _stream()))
+
+    def set_articulation(self, joints):
+        j = np.ascontiguousarray(joints, dtype=F).reshape(-1) if self.n_joints else np.zeros(1, dtype=F)
+        check(lib().dartk_model_set_articulation(self.handle, _abi.fptr(j), _stream()))
+
+    def set_transforms(self, T_mc, T_mf, T_fm):
+        a = np.ascontiguousarray(T_mc, dtype=F).reshape(12)
+        b = np.ascontiguousarray(T_mf, dtype=F).reshape(-1)
+        c = np.ascontiguousarray(T_fm, dtype=F).reshape(-1)
+        assert b.size == 12 * self.n_frames and c.size == 12 * self.n_frames
+        check(lib().dartk_model_set_transforms(self.handle, _abi.fptr(a), _abi.fptr(b), _abi.fptr(c), _stream()))
+
+    def get_transforms(self):
+        T_mc = np.zeros(12, dtype=F)
+        T_mf = np.zeros((self.n_frames, 12), dtype=F)
+        T_fm = np.zeros((self.n_frames, 12), dtype=F)
+        joints = np.zeros(max(self.n_joints, 1), dtype=F)
+        check(lib().dartk_model_get_transforms(self.handle, _abi.fptr(T_mc), _abi.fptr(T_mf), _abi.fptr(T_fm), _abi.fptr(joints)))
+        return T_mc, T_mf, T_fm, joints[:self.n_joints]
+
+
+def new_pts(n, device="cuda"):
+    """Device array of n DataAssociatedPoint records (12 B each)."""
+    return torch.empty((max(n, 1), 3), dtype=torch.int32, device=device)
+
+
+def pts_to_numpy(pts, count):
+    raw = pts[:count].cpu().numpy()
+    out = np.empty(count, dtype=_abi.DA_DTYPE)
+    out["index"] = raw[:, 0]
+    out["dataAssociation"] = raw[:, 1]
+    out["error"] = raw[:, 2].view(np.float32)
+    return out
+
+
+def pts_from_numpy(rec, device="cuda"):
+    raw = np.empty((len(rec), 3), dtype=np.int32)
+    raw[:, 0] = rec["index"]
+    raw[:, 1] = rec["dataAssociation"]
+    raw[:, 2] = rec["error"].astype(np.float32).view(np.int32)
+    return torch.from_numpy(raw).to(device)
+
+
+def error_and_data_association(vert, norm, model, dist_threshold=0.03, norm_threshold=-0.1, plane_offset=-0.03,
+                               plane_normal=(0, 0, 0), pts=None, debug=False):
+    """errorAndDataAssociation (obsToMod.h:75-86). vert/norm: float32 CUDA tensors [H,W,4].
+    Returns (pts tensor, count, debug dict)."""
+    h, w = vert.shape[0], vert.shape[1]
+    if pts is None:
+        pts = new_pts(h * w, vert.device)
+    last = torch.zeros(1, dtype=torch.int32, device=vert.device)
+    h_last = np.zeros(1, dtype=np.int32)
+    dbg = {}
+    if debug:
+        dbg["da"] = torch.empty((h, w), dtype=torch.int32, device=vert.device)
+        dbg["err"] = torch.empty((h, w), dtype=torch.float32, device=vert.device)
+        dbg["norm"] = torch.empty((h, w, 4), dtype=torch.float32, device=vert.device)
+    pn = np.asarray(plane_normal, dtype=F)
+    check(lib().dartk_assoc_single(_ptr(vert), _ptr(norm), w, h, model.handle, dist_threshold, norm_threshold,
+                                   plane_offset, _abi.fptr(pn), _ptr(pts), _ptr(last), _abi.iptr(h_last),
+                                   _ptr(dbg.get("da")), _ptr(dbg.get("err")), _ptr(dbg.get("norm")), _stream()))
+    return pts, int(h_last[0]), dbg
+
+
+def error_and_data_association_multi(vert, norm, models, dist_thresholds, plane_offsets, plane_normals, pts_list=None,
+                                     debug=False):
+    """errorAndDataAssociationMultiModel (obsToMod.h:88-107). Returns (pts list, counts, debug dict)."""
+    h, w = vert.shape[0], vert.shape[1]
+    n = len(models)
+    if pts_list is None:
+        pts_list = [new_pts(h * w, vert.device) for _ in range(n)]
+    last = torch.zeros(n, dtype=torch.int32, device=vert.device)
+    handles = (C.c_void_p * n)(*[m.handle for m in models])
+    table = (C.c_void_p * n)(*[C.c_void_p(p.data_ptr()) for p in pts_list])
+    dt = np.asarray(dist_thresholds, dtype=F)
+    po = np.asarray(plane_offsets, dtype=F)
+    pn = np.ascontiguousarray(plane_normals, dtype=F).reshape(-1)
+    dbg = {}
+    if debug:
+        dbg["da"] = torch.empty((h, w), dtype=torch.int32, device=vert.device)
+        dbg["err"] = torch.empty((h, w), dtype=torch.float32, device=vert.device)
+    check(lib().dartk_assoc_multi(_ptr(vert), _ptr(norm), w, h, n, handles, _abi.fptr(dt), _abi.fptr(po), _abi.fptr(pn),
+                                  table, _ptr(last), _ptr(dbg.get("da")), _ptr(dbg.get("err")), _stream()))
+    counts = last.cpu().numpy()
+    return pts_list, counts, dbg
+
+
+def sys_len(dims):
+    return dims + dims * (dims + 1) // 2 + 1
+
+
+def norm_eqns_obs_to_mod(vert, model, pts, n_elements, huber_delta=0.02, reduction=None, result=None):
+    """normEqnsObsToMod{,Reduced,ParamMap} (obsToMod.h:12-45). reduction = None | ("linear", A tensor, redDims) |
+    ("map", mapping tensor, redDims). Returns the packed system as a CUDA tensor."""
+    h, w = vert.shape[0], vert.shape[1]
+    dims = model.dims
+    rd = dims if reduction is None else reduction[2]
+    if result is None:
+        result = torch.empty(sys_len(rd), dtype=torch.float32, device=vert.device)
+    if reduction is None:
+        check(lib().dartk_ne_obs2mod(dims, _ptr(vert), w, h, model.handle, huber_delta, _ptr(pts), n_elements, _ptr(result), _stream()))
+    elif reduction[0] == "linear":
+        check(lib().dartk_ne_obs2mod_reduced(dims, rd, _ptr(reduction[1]), _ptr(vert), w, h, model.handle, huber_delta,
+                                             _ptr(pts), n_elements, _ptr(result), _stream()))
+    else:
+        check(lib().dartk_ne_obs2mod_parammap(dims, rd, _ptr(reduction[1]), _ptr(vert), w, h, model.handle, huber_delta,
+                                              _ptr(pts), n_elements, _ptr(result), _stream()))
+    return result

@@ -1,0 +1,185 @@
+/*
+ * dartk.h -- C ABI of libdartk.so: the MI355X (gfx950) implementation of DART's Gauss-Newton hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one of the reference's `namespace dart` free
+ * functions (or the MirroredModel device state they read); the comment above each cites the interface it
+ * replaces as file:line relative to the reference tree. Plain pointers and sizes only; `d_` arguments are
+ * device pointers, `h_` host pointers, `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * All functions return 0 on success or a negative dartk_status; dartk_last_error() describes the failure.
+ * Like the reference (optimizer.cpp:196-199, static scratch) a model handle is not re-entrant: calls that
+ * touch one handle must be issued from one host thread / one stream at a time.
+ *
+ * Conventions (reference Appendix-C layouts): SE3 = float[12] row-major [R|t] (SE3.h:17-23); vertex /
+ * normal / prediction maps = float4 per pixel (w>0 valid; prediction z==0 none, w = (model<<16)+sdf);
+ * packed system = float[dims + dims(dims+1)/2 + 1] = [J^T e | lower-tri J^T J at i(i+1)/2+j | e]
+ * (kernel_common.h:141-153, optimization.h:74).
+ */
+#ifndef DARTK_H
+#define DARTK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum dartk_status {
+    DARTK_OK = 0,
+    DARTK_ERR_INVALID = -1,   /* bad argument / shape mismatch (checked on the host before any launch) */
+    DARTK_ERR_HIP = -2,       /* a HIP runtime call failed */
+    DARTK_ERR_UNSUPPORTED = -3,
+    DARTK_ERR_NO_DEVICE = -4
+};
+
+#define DARTK_MAX_JOINTS 64   /* dependency rows are one 64-bit mask per frame */
+#define DARTK_MAX_MODELS 8
+
+/* optimization.h:85-89 */
+typedef struct { int32_t index; int32_t dataAssociation; float error; } dartk_da_point;
+
+typedef struct dartk_model_s *dartk_model_t;
+
+/* Everything MirroredModel's constructor copies to the device (mirrored_model.cpp:8-120). Host arrays. */
+typedef struct {
+    int32_t n_frames, n_joints, n_sdfs, model_id;
+    const int32_t *frame_parent;   /* [n_frames], root = -1 */
+    const int32_t *joint_type;     /* [n_joints] 0 rotational / 1 prismatic (dart_types.h:6-9) */
+    const float *joint_axis;       /* [n_joints*3] */
+    const float *T_pf;             /* [n_joints*12] joint-axis-to-parent transforms */
+    const float *dh;               /* [n_joints*4] a, alpha, d, theta (host_only_model.cpp:120-125) */
+    const float *joint_limits;     /* [n_joints*2] min,max */
+    const int32_t *sdf_frame;      /* [n_sdfs] */
+    const int32_t *dependencies;   /* [n_frames*n_joints] (host_only_model.cpp:97-103) */
+    const int32_t *sdf_dim;        /* [n_sdfs*3] */
+    const float *sdf_offset;       /* [n_sdfs*3] */
+    const float *sdf_resolution;   /* [n_sdfs] */
+    const float *const *sdf_data;  /* [n_sdfs] host pointers, voxel units, x fastest (grid_3d.h:82-84) */
+    int32_t obs_sdf_dim[3];        /* observation SDF (mirrored_model.cpp:111-118); dims 0 = none */
+    float obs_sdf_offset[3];
+    float obs_sdf_resolution;
+} dartk_model_desc;
+
+/* ------------------------------------------------------------------ library / device */
+int dartk_init(int device);                 /* hipSetDevice + workspace allocation; idempotent per device */
+const char *dartk_last_error(void);
+int dartk_version(void);
+
+/* MirroredVector<T> device side (util/mirrored_memory.h:36-83) */
+int dartk_buf_alloc(void **d_ptr, size_t bytes);
+int dartk_buf_free(void *d_ptr);
+int dartk_buf_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int dartk_buf_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int dartk_buf_zero(void *d_ptr, size_t bytes, void *stream);
+int dartk_stream_sync(void *stream);
+
+/* ------------------------------------------------------------------ model (src/model/mirrored_model.*) */
+int dartk_model_create(const dartk_model_desc *desc, dartk_model_t *out);        /* mirrored_model.cpp:8-120 */
+int dartk_model_destroy(dartk_model_t m);                                        /* :122-152 */
+/* MirroredModel::setPose (mirrored_model.cpp:185-225): clamps joints, GraspIt-DH forward kinematics ON DEVICE,
+ * fills T_mf/T_fm/T_mc/T_cm. h_T_mc = camera->model. */
+int dartk_model_set_pose(dartk_model_t m, const float *h_T_mc, const float *h_joints, void *stream);
+/* MirroredModel::setArticulation (mirrored_model.cpp:154-183): axis-angle FK variant; T_mc untouched. */
+int dartk_model_set_articulation(dartk_model_t m, const float *h_joints, void *stream);
+/* Upload host-computed transforms verbatim (what _T_mf/_T_fm->syncHostToDevice() does, :222-224). */
+int dartk_model_set_transforms(dartk_model_t m, const float *h_T_mc, const float *h_T_mf, const float *h_T_fm,
+                               void *stream);
+int dartk_model_get_transforms(dartk_model_t m, float *h_T_mc, float *h_T_mf, float *h_T_fm, float *h_joints);
+int dartk_model_num_sdfs(dartk_model_t m);
+int dartk_model_dims(dartk_model_t m);
+/* device pointer of the observation SDF data (MirroredModel::getDeviceObsSdfData) */
+float *dartk_model_obs_sdf_data(dartk_model_t m);
+
+/* ------------------------------------------------------------------ obs -> mod (kernels/obsToMod.h) */
+/* errorAndDataAssociation, obsToMod.h:75-86 / obsToMod.cu:504-555. Zeroes *d_last, appends associated points,
+ * copies the count to *h_last (blocking, like the reference) when h_last != NULL. Debug maps may be NULL. */
+int dartk_assoc_single(const float *d_vert, const float *d_norm, int width, int height, dartk_model_t m,
+                       float distThreshold, float normThreshold, float planeOffset, const float *h_planeNormal3,
+                       dartk_da_point *d_pts, int32_t *d_last, int32_t *h_last, int32_t *d_dbgDA,
+                       float *d_dbgErr, float *d_dbgNorm, void *stream);
+/* errorAndDataAssociationMultiModel, obsToMod.h:88-107 / obsToMod.cu:557-619. The per-model device pointer
+ * tables of the reference (T_fms, sdfFrames, sdfs, nSdfs) are the model handles; thresholds/planes are host
+ * arrays [nModels]; d_pts_table = device array of nModels device pointers. */
+int dartk_assoc_multi(const float *d_vert, const float *d_norm, int width, int height, int nModels,
+                      const dartk_model_t *models, const float *h_distThresholds, const float *h_planeOffsets,
+                      const float *h_planeNormals3, dartk_da_point *const *h_pts_table, int32_t *d_last,
+                      int32_t *d_dbgDA, float *d_dbgErr, void *stream);
+/* normEqnsObsToMod, obsToMod.h:12-21 / obsToMod.cu:621-697 (system zeroed; kernel only if nElements > 10). */
+int dartk_ne_obs2mod(int dims, const float *d_vert, int width, int height, dartk_model_t m, float huberDelta,
+                     const dartk_da_point *d_pts, int nElements, float *d_result, void *stream);
+/* normEqnsObsToModReduced, obsToMod.h:23-33 / obsToMod.cu:699-757. d_dtheta_dalpha: [(dims-6)*(redDims-6)],
+ * row = full joint (pose.cpp:66-73). */
+int dartk_ne_obs2mod_reduced(int dims, int redDims, const float *d_dtheta_dalpha, const float *d_vert, int width,
+                             int height, dartk_model_t m, float huberDelta, const dartk_da_point *d_pts,
+                             int nElements, float *d_result, void *stream);
+/* normEqnsObsToModParamMap, obsToMod.h:35-45 / obsToMod.cu:759-817. d_mapping: int[dims-6]. */
+int dartk_ne_obs2mod_parammap(int dims, int redDims, const int32_t *d_mapping, const float *d_vert, int width,
+                              int height, dartk_model_t m, float huberDelta, const dartk_da_point *d_pts,
+                              int nElements, float *d_result, void *stream);
+
+/* ------------------------------------------------------------------ mod -> obs (kernels/modToObs.h, raycast.h) */
+/* raycastPrediction, raycast.cu:440-466 (one call per model; modelNum 0 clears the map). */
+int dartk_raycast_prediction(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum,
+                             dartk_model_t m, float *d_prediction, float levelSet, void *stream);
+/* cullUnobservable_, modToObs.cu:1050-1064 */
+int dartk_cull_unobservable(float *d_pred, int predWidth, int predHeight, const float *d_obsVert, int obsWidth,
+                            int obsHeight, void *stream);
+/* Optimizer::generateObsSdfSplatZeroAndDistanceTransform, optimizer.cpp:168-219 = splatObsSdfZeros
+ * (modToObs.cu:990-1008) + distanceTransform3D<float,true> (distance_transforms.cu:434-458) + copy back.
+ * Uses the model's current T_cm. Obs-SDF dims must be multiples of (8,8,4) (modToObs.cu:998-999). */
+int dartk_obs_sdf_build(const float *d_vert, int width, int height, dartk_model_t m, float focalLength,
+                        void *stream);
+/* distanceTransform3D / signedDistanceTransform3D on device buffers (distance_transforms.h:16-29);
+ * d_in is clobbered as in the reference. */
+int dartk_distance_transform_3d(float *d_in, float *d_out, int width, int height, int depth, int takeSqrt,
+                                void *stream);
+int dartk_signed_distance_transform_3d(float *d_in, float *d_out, int width, int height, int depth,
+                                       int takeSqrt, void *stream);
+/* normEqnsModToObs, modToObs.h:13-30 / modToObs.cu:713-780. h_T_gc = camera -> obs-SDF frame. Zeroes the
+ * system and *d_numPredictions. */
+int dartk_ne_mod2obs(int dims, const float *d_pred, int width, int height, dartk_model_t m, const float *h_T_gc,
+                     float *d_result, int32_t *d_numPredictions, void *stream);
+/* normEqnsModToObsTruncated, modToObs.cu:782-849 (uses the model's T_mc) */
+int dartk_ne_mod2obs_truncated(int dims, const float *d_pred, int width, int height, dartk_model_t m,
+                               float truncationDistance, float *d_result, int32_t *d_numPredictions,
+                               void *stream);
+/* normEqnsModToObsReduced / ParamMap, modToObs.cu:851-988 (use the model's T_mc; counter NOT zeroed, A-19) */
+int dartk_ne_mod2obs_reduced(int dims, int redDims, const float *d_dtheta_dalpha, const float *d_pred, int width,
+                             int height, dartk_model_t m, float *d_result, int32_t *d_numPredictions,
+                             void *stream);
+int dartk_ne_mod2obs_parammap(int dims, int redDims, const int32_t *d_mapping, const float *d_pred, int width,
+                              int height, dartk_model_t m, float *d_result, int32_t *d_numPredictions,
+                              void *stream);
+/* errorModToObs, modToObs.cu:1030-1048: returns 0.5*sum err^2 in *h_error */
+int dartk_error_mod2obs(const float *d_pred, int width, int height, dartk_model_t m, float *h_error,
+                        void *stream);
+
+/* ------------------------------------------------------------------ intersection (kernels/intersection.h) */
+/* normEqnsSelfIntersection{,Reduced,ParamMap}, intersection.cu:765-890. Result is the (dims-6) system. */
+int dartk_ne_self_intersection(const float *d_sites, int nSites, int dims, dartk_model_t m,
+                               const int32_t *d_potentialIntersection, float *d_result, void *stream);
+int dartk_ne_self_intersection_reduced(const float *d_sites, int nSites, int fullDims, int redDims,
+                                       dartk_model_t m, const float *d_dtheta_dalpha,
+                                       const int32_t *d_potentialIntersection, float *d_result, void *stream);
+int dartk_ne_self_intersection_parammap(const float *d_sites, int nSites, int fullDims, int redDims,
+                                        dartk_model_t m, const int32_t *d_mapping,
+                                        const int32_t *d_potentialIntersection, float *d_result, void *stream);
+/* normEqnsIntersection{,Reduced,ParamMap}, intersection.cu:792-947. T_ds/T_sd host SE3 (optimizer.cpp:396-397). */
+int dartk_ne_intersection(const float *d_sites, int nSites, int dims, const float *h_T_ds, const float *h_T_sd,
+                          dartk_model_t src, dartk_model_t dst, float *d_result, void *stream);
+int dartk_ne_intersection_reduced(const float *d_sites, int nSites, int fullDims, int redDims,
+                                  const float *h_T_ds, const float *h_T_sd, dartk_model_t src, dartk_model_t dst,
+                                  const float *d_dtheta_dalpha, float *d_result, void *stream);
+int dartk_ne_intersection_parammap(const float *d_sites, int nSites, int fullDims, int redDims,
+                                   const float *h_T_ds, const float *h_T_sd, dartk_model_t src, dartk_model_t dst,
+                                   const int32_t *d_mapping, float *d_result, void *stream);
+/* countSelfIntersections / countIntersections, intersection.cu:715-763 (blocking; return the count) */
+int dartk_count_self_intersections(const float *d_sites, int nSites, dartk_model_t m,
+                                   const int32_t *d_potentialIntersection, int32_t *h_count, void *stream);
+int dartk_count_intersections(const float *d_sites, int nSites, const float *h_T_ds, dartk_model_t src,
+                              dartk_model_t dst, int32_t *h_count, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DARTK_H */

@@ -1,0 +1,194 @@
+"""ctypes wrapper of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY (never imported by dart_amd/)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from dart_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+F = np.float32
+fp = _abi.c_float_p
+ip = _abi.c_int_p
+vp = C.c_void_p
+
+
+class OrcGrid(C.Structure):
+    _fields_ = [("dim", C.c_int32 * 3), ("offset", C.c_float * 3), ("resolution", C.c_float), ("data", fp)]
+
+
+class OrcModel(C.Structure):
+    _fields_ = list(_abi.ModelDesc._fields_)   # identical field order by construction (oracle/dart_oracle.h)
+
+
+class OrcContactPrior(C.Structure):
+    _fields_ = [("srcModel", C.c_int32), ("dstModel", C.c_int32), ("srcSdf", C.c_int32), ("weight", C.c_float),
+                ("contactPoint", C.c_float * 3), ("normal", C.c_float * 3), ("invert", C.c_int32),
+                ("contactThreshold", C.c_float), ("updateSrc", C.c_int32), ("updateDst", C.c_int32),
+                ("updateContact", C.c_int32)]
+
+
+def build():
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h")) or f == "Makefile"]
+    if not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_grid_value_interp.restype = C.c_float
+        L.orc_error_mod2obs.restype = C.c_float
+        L.orc_unpack.restype = C.c_float
+        L.orc_contact_prior_contribution.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+def f(a):
+    return a.ctypes.data_as(fp)
+
+
+def i(a):
+    return a.ctypes.data_as(ip)
+
+
+def c32(a):
+    return np.ascontiguousarray(a, dtype=F)
+
+
+class OModel:
+    """orc_model built from a dart_amd HostModel (shares the flat arrays the product uploads)."""
+
+    def __init__(self, host_model, model_id=0, obs_layout=None):
+        self.host = host_model
+        self.desc, self.keep = _abi.fill_model_desc(OrcModel, host_model, model_id, obs_layout)
+        self.n_frames, self.n_joints, self.n_sdfs = host_model.n_frames, host_model.n_joints, len(host_model.sdfs)
+        self.dims = 6 + self.n_joints
+        self.model_id = model_id
+
+    @property
+    def ref(self):
+        return C.byref(self.desc)
+
+    def fk(self, joints, mode="dh"):
+        j = c32(joints) if self.n_joints else np.zeros(1, dtype=F)
+        T_mf = np.zeros((self.n_frames, 12), dtype=F)
+        T_fm = np.zeros((self.n_frames, 12), dtype=F)
+        fn = lib().orc_fk_set_pose if mode == "dh" else lib().orc_fk_set_articulation
+        fn(self.ref, f(j), f(T_mf), f(T_fm))
+        return T_mf, T_fm
+
+    def grid(self, s):
+        g = self.host.sdfs[s]
+        return make_grid(g.dim, g.offset, g.resolution, g.data)
+
+
+def make_grid(dim, offset, res, data):
+    data = np.ascontiguousarray(data, dtype=F)
+    g = OrcGrid()
+    for k in range(3):
+        g.dim[k] = int(dim[k])
+        g.offset[k] = float(offset[k])
+    g.resolution = float(res)
+    g.data = f(data)
+    g._keep = data
+    return g
+
+
+def se3_invert(T):
+    out = np.zeros(12, dtype=F)
+    lib().orc_se3_invert(f(c32(T)), f(out))
+    return out
+
+
+def se3_mul(A, B):
+    out = np.zeros(12, dtype=F)
+    lib().orc_se3_mul(f(c32(A)), f(c32(B)), f(out))
+    return out
+
+
+def se3_exp(t6):
+    out = np.zeros(12, dtype=F)
+    lib().orc_se3_exp(f(c32(t6)), f(out))
+    return out
+
+
+def sys_len(d):
+    return d + d * (d + 1) // 2 + 1
+
+
+def assoc_single(vert, norm, om, T_mc, T_fm, dist_thr=0.03, norm_thr=-0.1, plane_offset=-0.03, plane_normal=(0, 0, 0), debug=True):
+    h, w = vert.shape[:2]
+    pts = np.zeros(h * w, dtype=_abi.DA_DTYPE)
+    dbgDA = np.zeros((h, w), dtype=np.int32)
+    dbgErr = np.zeros((h, w), dtype=F)
+    dbgNorm = np.zeros((h, w, 4), dtype=F)
+    pn = c32(plane_normal)
+    lib().orc_assoc_single.restype = C.c_int
+    n = lib().orc_assoc_single(f(c32(vert)), f(c32(norm)), w, h, om.ref, f(c32(T_mc)), f(c32(T_fm)),
+                               C.c_float(dist_thr), C.c_float(norm_thr), C.c_float(plane_offset), f(pn),
+                               pts.ctypes.data_as(vp), i(dbgDA), f(dbgErr), f(dbgNorm))
+    return pts[:n].copy(), {"da": dbgDA, "err": dbgErr, "norm": dbgNorm}
+
+
+def assoc_multi(vert, oms, T_mcs, T_fms, dist_thrs, plane_offsets, plane_normals):
+    h, w = vert.shape[:2]
+    n = len(oms)
+    pts = [np.zeros(h * w, dtype=_abi.DA_DTYPE) for _ in range(n)]
+    counts = np.zeros(n, dtype=np.int32)
+    dbgDA = np.zeros((h, w), dtype=np.int32)
+    dbgErr = np.zeros((h, w), dtype=F)
+    models = (C.POINTER(OrcModel) * n)(*[C.pointer(o.desc) for o in oms])
+    T_mcs = c32(np.asarray(T_mcs).reshape(n, 12))
+    T_fm_keep = [c32(t) for t in T_fms]
+    T_fm_ptrs = (fp * n)(*[f(t) for t in T_fm_keep])
+    pts_ptrs = (vp * n)(*[p.ctypes.data_as(vp) for p in pts])
+    lib().orc_assoc_multi(f(c32(vert)), None, w, h, n, models, f(T_mcs), T_fm_ptrs, f(c32(dist_thrs)), f(c32(plane_offsets)),
+                          f(c32(np.asarray(plane_normals).reshape(-1))), pts_ptrs, i(counts), i(dbgDA), f(dbgErr))
+    return [p[:c].copy() for p, c in zip(pts, counts)], counts, {"da": dbgDA, "err": dbgErr}
+
+
+def _red_args(reduction):
+    if reduction is None:
+        return 0, 0, None, None, ()
+    kind, arr, rd = reduction
+    if kind == "linear":
+        a = c32(arr)
+        return 1, rd, f(a), None, (a,)
+    m = np.ascontiguousarray(arr, dtype=np.int32)
+    return 2, rd, None, i(m), (m,)
+
+
+def ne_obs2mod(vert, om, T_mc, T_fm, T_mf, pts, huber_delta=0.02, reduction=None):
+    red, rd, A, mp, keep = _red_args(reduction)
+    d = rd if red else om.dims
+    res = np.zeros(sys_len(d), dtype=F)
+    pts = np.ascontiguousarray(pts)
+    lib().orc_ne_obs2mod(f(c32(vert)), om.ref, f(c32(T_mc)), f(c32(T_fm)), f(c32(T_mf)), pts.ctypes.data_as(vp), len(pts),
+                         C.c_float(huber_delta), red, rd, A, mp, f(res))
+    return res
+
+
+def error_jacobian(om, T_fm, T_mf, point_m, frame, grad_m, articulation_only=False):
+    n = om.n_joints if articulation_only else om.dims
+    J = np.zeros(max(n, 1), dtype=F)
+    p4 = c32(list(point_m[:3]) + [1.0 if len(point_m) < 4 else point_m[3]])
+    lib().orc_error_jacobian(om.ref, f(c32(T_fm)), f(c32(T_mf)), f(p4), int(frame), f(c32(grad_m)), int(articulation_only), f(J))
+    return J[:n]
+
+
+def model_jacobian_3d(om, T_fm, T_mf, point_m, frame):
+    J = np.zeros((om.dims, 3), dtype=F)
+    p4 = c32(list(point_m[:3]) + [1.0])
+    lib().orc_model_jacobian_3d(om.ref, f(c32(T_fm)), f(c32(T_mf)), f(p4), int(frame), f(J))
+    return J

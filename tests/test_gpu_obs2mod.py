@@ -1,0 +1,170 @@
+"""GPU parity: observation-to-model association and its normal equations, through the C ABI, vs the CPU oracle.
+Bars (BASELINE.json north_star): association indices bit-exact (near-ties documented), J^T J / J^T e within 1e-4
+relative (norm-relative per block), counts equal."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import scenes
+from dart_amd import device as D
+from dart_amd import se3
+
+F = np.float32
+pytestmark = pytest.mark.gpu
+
+
+def rel_err_blocks(got, ref, dims):
+    """max over {J^T e, J^T J, e} of ||got-ref|| / ||ref|| (norm-relative per block)."""
+    out = 0.0
+    for sl in (slice(0, dims), slice(dims, len(ref) - 1), slice(len(ref) - 1, len(ref))):
+        n = np.linalg.norm(ref[sl].astype(np.float64))
+        d = np.linalg.norm(got[sl].astype(np.float64) - ref[sl].astype(np.float64))
+        out = max(out, d / n if n > 0 else d)
+    return out
+
+
+def sorted_pts(p):
+    return p[np.argsort(p["index"], kind="stable")]
+
+
+def test_fk_matches_oracle(gpu):
+    for name in ("allegro", "human_hand", "barrett", "left_hand"):
+        m = scenes.articulated(name)
+        om = O.OModel(m)
+        dm = D.DeviceModel(m, model_id=0)
+        for seed in range(3):
+            joints = scenes.random_joints(m, seed, margin=-0.05)     # some beyond the limits: clamping is exercised
+            T_mc = scenes.random_T(seed, base=(0, 0, -0.5))
+            dm.set_pose(T_mc, joints)
+            g_mc, g_mf, g_fm, g_j = dm.get_transforms()
+            o_mf, o_fm = om.fk(joints, "dh")
+            assert np.array_equal(g_mc, T_mc)
+            np.testing.assert_allclose(g_mf, o_mf, atol=2e-6)
+            np.testing.assert_allclose(g_fm, o_fm, atol=2e-6)
+            lim = np.asarray(m.joint_limits, dtype=F)
+            assert np.array_equal(g_j, np.clip(joints, lim[:, 0], lim[:, 1]))
+            dm.set_articulation(joints)
+            _, g_mf, g_fm, _ = dm.get_transforms()
+            o_mf, o_fm = om.fk(joints, "axis")
+            np.testing.assert_allclose(g_mf, o_mf, atol=2e-6)
+            np.testing.assert_allclose(g_fm, o_fm, atol=2e-6)
+
+
+def test_sphere_association_kat_and_bitexact(gpu):
+    """The reference's own kernel test (test_obs_to_mod_kernels.cpp) on the GPU path + bit-exactness vs the oracle."""
+    m = scenes.sphere()
+    om = O.OModel(m)
+    dm = D.DeviceModel(m, model_id=0)
+    dm.set_pose(se3.identity(), np.zeros(0, dtype=F))
+    _, T_mf, T_fm, _ = dm.get_transforms()
+    for seed, (w, h) in enumerate([(10, 10), (64, 48), (640, 480)]):
+        vert = scenes.random_vertex_map(w, h, seed)
+        norm = np.zeros_like(vert)
+        pts, count, dbg = D.error_and_data_association(torch.from_numpy(vert).to(gpu), torch.from_numpy(norm).to(gpu), dm,
+                                                       dist_threshold=0.05, debug=True)
+        da = dbg["da"].cpu().numpy().reshape(-1)
+        err = dbg["err"].cpu().numpy().reshape(-1)
+        p = vert.reshape(-1, 4)
+        dist = np.linalg.norm(p[:, :3].astype(np.float64), axis=1) - 0.1
+        invalid = p[:, 3] == 0
+        assert np.all(da[invalid] == -1) and np.all(np.isnan(err[invalid]))
+        clear_in = (~invalid) & (np.abs(dist) < 0.05 - 0.005 / 8)
+        clear_out = (~invalid) & (np.abs(dist) > 0.05 + 0.005 / 8)
+        assert np.all(da[clear_in] == 0)
+        assert np.all(np.abs(err[clear_in] - dist[clear_in]) < 0.005 / 8)
+        assert np.all(da[clear_out] == -1) and np.all(np.isnan(err[clear_out]))
+        # oracle: identical indices and bit-identical errors
+        o_pts, o_dbg = O.assoc_single(vert, norm, om, se3.identity(), T_fm, dist_thr=0.05)
+        g_pts = sorted_pts(D.pts_to_numpy(pts, count))
+        assert count == len(o_pts)
+        assert np.array_equal(g_pts["index"], o_pts["index"])
+        assert np.array_equal(g_pts["dataAssociation"], o_pts["dataAssociation"])
+        assert np.array_equal(g_pts["error"].view(np.int32), o_pts["error"].view(np.int32))
+        assert np.array_equal(da, o_dbg["da"].reshape(-1))
+
+
+@pytest.mark.parametrize("name", ["allegro", "left_hand", "human_hand", "barrett"])
+def test_articulated_association_and_normal_equations(gpu, name):
+    m = scenes.articulated(name)
+    om = O.OModel(m)
+    dm = D.DeviceModel(m, model_id=0)
+    for seed, (w, h) in enumerate([(160, 120), (320, 240)]):
+        joints = scenes.random_joints(m, 10 + seed)
+        T_mc = scenes.random_T(20 + seed, base=(0, 0, -0.5))
+        dm.set_pose(T_mc, joints)
+        g_mc, T_mf, T_fm, _ = dm.get_transforms()          # the oracle consumes the SAME transforms (FK tested above)
+        vert = scenes.points_near_model(m, T_mf, se3.invert(T_mc), w, h, seed)
+        norm = scenes.random_normal_map(w, h, seed)
+        v_d, n_d = torch.from_numpy(vert).to(gpu), torch.from_numpy(norm).to(gpu)
+        pts, count, dbg = D.error_and_data_association(v_d, n_d, dm, dist_threshold=0.03, norm_threshold=-0.1, debug=True)
+        o_pts, o_dbg = O.assoc_single(vert, norm, om, T_mc, T_fm, dist_thr=0.03, norm_thr=-0.1)
+        g_pts = sorted_pts(D.pts_to_numpy(pts, count))
+        assert count == len(o_pts) and count > 200
+        assert np.array_equal(g_pts["index"], o_pts["index"])
+        assert np.array_equal(g_pts["dataAssociation"], o_pts["dataAssociation"])
+        assert np.array_equal(g_pts["error"].view(np.int32), o_pts["error"].view(np.int32))
+        assert len(np.unique(g_pts["dataAssociation"])) >= min(4, len(m.sdfs))
+        np.testing.assert_array_equal(dbg["norm"].cpu().numpy().view(np.int32), o_dbg["norm"].view(np.int32))
+        # normal equations over the GPU's own (unsorted) list == oracle over the sorted list
+        res = D.norm_eqns_obs_to_mod(v_d, dm, pts, count, huber_delta=0.02).cpu().numpy()
+        ref = O.ne_obs2mod(vert, om, T_mc, T_fm, T_mf, o_pts, huber_delta=0.02)
+        assert np.abs(g_pts["error"]).max() > 0.02          # the Huber outlier branch is exercised
+        assert rel_err_blocks(res, ref, m.dims) < 1e-4
+        # deterministic: a second launch gives the same bits
+        res2 = D.norm_eqns_obs_to_mod(v_d, dm, pts, count, huber_delta=0.02).cpu().numpy()
+        assert np.array_equal(res.view(np.int32), res2.view(np.int32))
+
+
+def test_normal_equations_gate_and_edge_cases(gpu):
+    m = scenes.articulated("allegro")
+    om = O.OModel(m)
+    dm = D.DeviceModel(m, model_id=0)
+    joints = scenes.random_joints(m, 1)
+    T_mc = scenes.random_T(2, base=(0, 0, -0.5))
+    dm.set_pose(T_mc, joints)
+    _, T_mf, T_fm, _ = dm.get_transforms()
+    vert = scenes.points_near_model(m, T_mf, se3.invert(T_mc), 64, 48, 5)
+    norm = np.zeros_like(vert)
+    v_d = torch.from_numpy(vert).to(gpu)
+    o_pts, _ = O.assoc_single(vert, norm, om, T_mc, T_fm)
+    for n in (0, 5, 10, 11, 127, 128, 129, len(o_pts)):     # <=10 => zero system (obsToMod.cu:646); ragged tiles
+        sub = o_pts[:n]
+        res = D.norm_eqns_obs_to_mod(v_d, dm, D.pts_from_numpy(sub, gpu), n).cpu().numpy()
+        ref = O.ne_obs2mod(vert, om, T_mc, T_fm, T_mf, sub)
+        if n <= 10:
+            assert not res.any() and not ref.any()
+        else:
+            assert rel_err_blocks(res, ref, m.dims) < 1e-4
+    # empty / all-invalid observation
+    empty = torch.zeros((48, 64, 4), dtype=torch.float32, device=gpu)
+    _, count, _ = D.error_and_data_association(empty, empty, dm)
+    assert count == 0
+
+
+def test_reduced_and_parammap_normal_equations(gpu):
+    m = scenes.articulated("barrett")
+    om = O.OModel(m)
+    dm = D.DeviceModel(m, model_id=0)
+    joints = scenes.random_joints(m, 3)
+    T_mc = scenes.random_T(4, base=(0, 0, -0.5))
+    dm.set_pose(T_mc, joints)
+    _, T_mf, T_fm, _ = dm.get_transforms()
+    vert = scenes.points_near_model(m, T_mf, se3.invert(T_mc), 160, 120, 6)
+    norm = np.zeros_like(vert)
+    v_d = torch.from_numpy(vert).to(gpu)
+    pts, count, _ = D.error_and_data_association(v_d, torch.from_numpy(norm).to(gpu), dm)
+    o_pts, _ = O.assoc_single(vert, norm, om, T_mc, T_fm)
+    # Barrett's 8 -> 4 coupling (grasp_analyzer.cpp:409-417): A[r + f*4]
+    A = np.zeros((8, 4), dtype=F)
+    for f, r, c in [(0, 0, 1), (3, 0, 1), (1, 1, 1), (2, 1, 1 / 3), (4, 2, 1), (5, 2, 1 / 3), (6, 3, 1), (7, 3, 1 / 3)]:
+        A[f, r] = c
+    red = ("linear", torch.from_numpy(A.reshape(-1)).to(gpu), 10)
+    res = D.norm_eqns_obs_to_mod(v_d, dm, pts, count, reduction=red).cpu().numpy()
+    ref = O.ne_obs2mod(vert, om, T_mc, T_fm, T_mf, o_pts, reduction=("linear", A.reshape(-1), 10))
+    assert rel_err_blocks(res, ref, 10) < 1e-4
+    mapping = np.array([0, 1, 1, 0, 2, 2, 3, 3], dtype=np.int32)
+    redm = ("map", torch.from_numpy(mapping).to(gpu), 10)
+    res = D.norm_eqns_obs_to_mod(v_d, dm, pts, count, reduction=redm).cpu().numpy()
+    ref = O.ne_obs2mod(vert, om, T_mc, T_fm, T_mf, o_pts, reduction=("map", mapping, 10))
+    assert rel_err_blocks(res, ref, 10) < 1e-4
