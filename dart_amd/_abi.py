@@ -103,6 +103,24 @@ def lib():
         "dartk_ne_obs2mod": [C.c_int, vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp],
         "dartk_ne_obs2mod_reduced": [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp],
         "dartk_ne_obs2mod_parammap": [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp],
+        "dartk_raycast_prediction": [C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp],
+        "dartk_cull_unobservable": [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp],
+        "dartk_obs_sdf_build": [vp, C.c_int, C.c_int, vp, C.c_float, vp],
+        "dartk_distance_transform_3d": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp],
+        "dartk_signed_distance_transform_3d": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp],
+        "dartk_ne_mod2obs": [C.c_int, vp, C.c_int, C.c_int, vp, c_float_p, vp, vp, vp],
+        "dartk_ne_mod2obs_truncated": [C.c_int, vp, C.c_int, C.c_int, vp, C.c_float, vp, vp, vp],
+        "dartk_ne_mod2obs_reduced": [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp],
+        "dartk_ne_mod2obs_parammap": [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp],
+        "dartk_error_mod2obs": [vp, C.c_int, C.c_int, vp, c_float_p, vp],
+        "dartk_ne_self_intersection": [vp, C.c_int, C.c_int, vp, vp, vp, vp],
+        "dartk_ne_self_intersection_reduced": [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp],
+        "dartk_ne_self_intersection_parammap": [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp],
+        "dartk_ne_intersection": [vp, C.c_int, C.c_int, c_float_p, c_float_p, vp, vp, vp, vp],
+        "dartk_ne_intersection_reduced": [vp, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, vp, vp, vp, vp, vp],
+        "dartk_ne_intersection_parammap": [vp, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, vp, vp, vp, vp, vp],
+        "dartk_count_self_intersections": [vp, C.c_int, vp, vp, c_int_p, vp],
+        "dartk_count_intersections": [vp, C.c_int, c_float_p, vp, vp, c_int_p, vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)

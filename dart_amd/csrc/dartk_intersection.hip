@@ -1,0 +1,358 @@
+// dartk_intersection.hip -- self- and inter-model intersection terms.
+// Replaces: optimization/kernels/intersection.cu (kernels :11-597, host wrappers :715-947).
+#include "dartk_internal.h"
+#include "dartk_reduce.h"
+#include "dartk_kernels.h"
+
+namespace dartk {
+
+struct Collision {
+    bool hit;
+    int dstGrid;
+    float residual;
+    f3 vg;        // grid coordinates in the penetrated SDF
+};
+
+// First penetrated destination SDF of a point given in the destination model's frame
+// (intersection.cu:100-142 / :405-441). pot == nullptr means "test every SDF" (inter-model case).
+__device__ __forceinline__ Collision first_collision(const ModelView &dst, const float *T_fm_dst, f3 v_dm,
+                                                     const int *__restrict__ pot, int srcGrid) {
+    Collision c;
+    c.hit = false; c.dstGrid = -1; c.residual = 0.0f; c.vg.x = c.vg.y = c.vg.z = 0.0f;
+    const int n = dst.nSdfs;
+    for (int g = 0; g < n; ++g) {
+        if (pot && !pot[g + srcGrid * n]) continue;
+        const int f = dst.sdfFrame[g];
+        const f3 vd = se3_apply_w(T_fm_dst + 12 * f, v_dm.x, v_dm.y, v_dm.z, 1.0f);
+        const SdfDev &s = dst.sdfs[g];
+        const f3 vg = grid_coords(s, vd);
+        if (!in_bounds_grad_interp(s, vg)) continue;
+        const float r = grid_value(dst.grids + s.dataOff, s.dimx, s.dimy, vg) * s.res;
+        if (r < 0) { c.hit = true; c.dstGrid = g; c.residual = r; c.vg = vg; break; }
+    }
+    return c;
+}
+
+// SELF: articulation-only system of size dims-6 (intersection.cu:66-300).
+template <int PPT, int RED>
+__global__ void __launch_bounds__(NE_BLOCK)
+ne_self_intersection_kernel(const float4 *__restrict__ sites, int nSites, ModelView m, const int *__restrict__ pot,
+                            int redDims, const float *__restrict__ dtheta_dalpha, const int *__restrict__ mapping,
+                            float *__restrict__ slabs) {
+    extern __shared__ float lds[];
+    const int fullDims = 6 + m.nJoints;
+    const int d = (RED ? redDims : fullDims) - 6;
+    const int ld = row_len(d, false);
+    float *sT_fm = lds;
+    float *sT_mf = sT_fm + 12 * m.nFrames;
+    const int fullLd = (fullDims - 6) | 1;
+    float *sFull = sT_mf + 12 * m.nFrames;
+    float *rows = sFull + (RED ? NE_BLOCK * fullLd : 0);
+    int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ld);
+    stage_model(m, sT_fm, sT_mf, nullptr);
+    __syncthreads();
+    PairAcc<NE_BLOCK, PPT> acc;
+    acc.init(d, false);
+    const int nTiles = (nSites + NE_BLOCK - 1) / NE_BLOCK;
+    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        const int index = tile * NE_BLOCK + threadIdx.x;
+        Collision c; c.hit = false;
+        f3 vm; vm.x = vm.y = vm.z = 0.f;
+        int srcFrame = 0;
+        if (index < nSites) {
+            const float4 v = sites[index];
+            const int srcGrid = (int)roundf(v.w);
+            srcFrame = m.sdfFrame[srcGrid];
+            vm = se3_apply_w(sT_mf + 12 * srcFrame, v.x, v.y, v.z, 1.0f);
+            c = first_collision(m, sT_fm, vm, pot, srcGrid);
+        }
+        int nActive;
+        const int slot = compact_slot<NE_BLOCK>(c.hit, waveCnt, nActive);
+        if (c.hit) {
+            float *row = rows + slot * ld;
+            const SdfDev &s = m.sdfs[c.dstGrid];
+            const int dstFrame = m.sdfFrame[c.dstGrid];
+            const f3 gf = grid_gradient(m.grids + s.dataOff, s.dimx, s.dimy, c.vg);
+            const f3 gm = se3_rotate(sT_mf + 12 * dstFrame, gf);
+            float *Jfull = RED ? (sFull + threadIdx.x * fullLd) : row;
+            error_jacobian<true>(Jfull, vm, 1.0f, m.depMask[srcFrame], gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
+            if (RED) reduce_jacobian<RED>(row, Jfull, 0, fullDims, redDims, dtheta_dalpha, mapping);
+            row[d] = c.residual;
+            row[d + 1] = (float)(0.5 * (double)c.residual * (double)c.residual);
+            row[d + 2] = 1.0f;
+        }
+        __syncthreads();
+        if (nActive) acc.accumulate(rows, ld, nActive);
+        __syncthreads();
+    }
+    acc.store(slabs + (size_t)blockIdx.x * sys_size(d), sys_size(d));
+}
+
+// INTER-MODEL: source cloud in destination SDFs, full source-pose system (intersection.cu:367-597).
+template <int PPT, int RED>
+__global__ void __launch_bounds__(NE_BLOCK)
+ne_intersection_kernel(const float4 *__restrict__ sites, int nSites, ModelView src, ModelView dst,
+                       const float *__restrict__ T_ds_sd /* [24] */, int redDims, const float *__restrict__ dtheta_dalpha,
+                       const int *__restrict__ mapping, float *__restrict__ slabs) {
+    extern __shared__ float lds[];
+    const int fullDims = 6 + src.nJoints;
+    const int d = RED ? redDims : fullDims;
+    const int ld = row_len(d, false);
+    float *sT_fm = lds;                               // source transforms
+    float *sT_mf = sT_fm + 12 * src.nFrames;
+    float *dT_fm = sT_mf + 12 * src.nFrames;          // destination transforms
+    float *dT_mf = dT_fm + 12 * dst.nFrames;
+    const int fullLd = fullDims | 1;
+    float *sFull = dT_mf + 12 * dst.nFrames;
+    float *rows = sFull + (RED ? NE_BLOCK * fullLd : 0);
+    int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ld);
+    stage_model(src, sT_fm, sT_mf, nullptr);
+    stage_model(dst, dT_fm, dT_mf, nullptr);
+    float T_ds[12], T_sd[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { T_ds[i] = T_ds_sd[i]; T_sd[i] = T_ds_sd[12 + i]; }
+    __syncthreads();
+    PairAcc<NE_BLOCK, PPT> acc;
+    acc.init(d, false);
+    const int nTiles = (nSites + NE_BLOCK - 1) / NE_BLOCK;
+    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        const int index = tile * NE_BLOCK + threadIdx.x;
+        Collision c; c.hit = false;
+        f3 vsm; vsm.x = vsm.y = vsm.z = 0.f;
+        int srcFrame = 0;
+        if (index < nSites) {
+            const float4 v = sites[index];
+            const int srcGrid = (int)roundf(v.w);
+            srcFrame = src.sdfFrame[srcGrid];
+            vsm = se3_apply_w(sT_mf + 12 * srcFrame, v.x, v.y, v.z, 1.0f);
+            const f3 vdm = se3_apply_w(T_ds, vsm.x, vsm.y, vsm.z, 1.0f);
+            c = first_collision(dst, dT_fm, vdm, nullptr, 0);
+        }
+        int nActive;
+        const int slot = compact_slot<NE_BLOCK>(c.hit, waveCnt, nActive);
+        if (c.hit) {
+            float *row = rows + slot * ld;
+            const SdfDev &s = dst.sdfs[c.dstGrid];
+            const int dstFrame = dst.sdfFrame[c.dstGrid];
+            const f3 gf = grid_gradient(dst.grids + s.dataOff, s.dimx, s.dimy, c.vg);
+            const f3 gdm = se3_rotate(dT_mf + 12 * dstFrame, gf);
+            const f3 gsm = se3_rotate(T_sd, gdm);
+            float *Jfull = RED ? (sFull + threadIdx.x * fullLd) : row;
+            error_jacobian<false>(Jfull, vsm, 1.0f, src.depMask[srcFrame], gsm, src.nJoints, src.jointType, src.jointAxis, sT_fm, sT_mf);
+            if (RED) reduce_jacobian<RED>(row, Jfull, 6, fullDims, redDims, dtheta_dalpha, mapping);
+            row[d] = c.residual;
+            row[d + 1] = (float)(0.5 * (double)c.residual * (double)c.residual);
+            row[d + 2] = 1.0f;
+        }
+        __syncthreads();
+        if (nActive) acc.accumulate(rows, ld, nActive);
+        __syncthreads();
+    }
+    acc.store(slabs + (size_t)blockIdx.x * sys_size(d), sys_size(d));
+}
+
+// counters (intersection.cu:11-64, :315-365)
+__global__ void count_self_kernel(const float4 *__restrict__ sites, int nSites, ModelView m, const int *__restrict__ pot, int *__restrict__ n) {
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
+    if (index < nSites) {
+        const float4 v = sites[index];
+        const int srcGrid = (int)roundf(v.w);
+        const f3 vm = se3_apply_w(m.T_mf + 12 * m.sdfFrame[srcGrid], v.x, v.y, v.z, 1.0f);
+        hit = first_collision(m, m.T_fm, vm, pot, srcGrid).hit;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(n, __popcll(mask));
+}
+__global__ void count_inter_kernel(const float4 *__restrict__ sites, int nSites, ModelView src, ModelView dst,
+                                   const float *__restrict__ T_ds, int *__restrict__ n) {
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
+    if (index < nSites) {
+        const float4 v = sites[index];
+        const int srcGrid = (int)roundf(v.w);
+        const f3 vsm = se3_apply_w(src.T_mf + 12 * src.sdfFrame[srcGrid], v.x, v.y, v.z, 1.0f);
+        const f3 vdm = se3_apply_w(T_ds, vsm.x, vsm.y, vsm.z, 1.0f);
+        hit = first_collision(dst, dst.T_fm, vdm, nullptr, 0).hit;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(n, __popcll(mask));
+}
+
+static int check_sites(const Model *m, int nSites) {
+    DARTK_REQUIRE(m != nullptr, "null model");
+    DARTK_REQUIRE(nSites >= 0, "negative site count");
+    return DARTK_OK;
+}
+
+template <int RED>
+static int launch_self(const float *d_sites, int nSites, int fullDims, int redDims, Model *mod, const float *d_A,
+                       const int *d_map, const int *d_pot, float *d_result, hipStream_t st) {
+    const ModelView &m = mod->v;
+    DARTK_REQUIRE(fullDims == 6 + m.nJoints, "dims %d does not match the model's 6+%d", fullDims, m.nJoints);
+    const int d = (RED ? redDims : fullDims) - 6;
+    DARTK_REQUIRE(d >= 1 && d + 6 <= kMaxDims, "articulated system dimension %d out of range", d);
+    const int S = sys_size(d);
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    if (nSites == 0) { DARTK_HIP(hipMemsetAsync(d_result, 0, S * sizeof(float), st)); return DARTK_OK; }
+    const int nTiles = (nSites + NE_BLOCK - 1) / NE_BLOCK;
+    const int nBlocks = nTiles < kMaxPartialBlocks ? nTiles : kMaxPartialBlocks;
+    rc = ensure_partials(ws, (size_t)nBlocks * S);
+    if (rc) return rc;
+    size_t words = 24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8;
+    if (RED) words += (size_t)NE_BLOCK * ((fullDims - 6) | 1);
+    const size_t ldsBytes = words * sizeof(float);
+    DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
+#define DARTK_LAUNCH_SELF(PPT_)                                                                                 \
+    do {                                                                                                        \
+        auto kfn = ne_self_intersection_kernel<PPT_, RED>;                                                      \
+        if (ldsBytes > 64 * 1024)                                                                               \
+            DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, m, d_pot, \
+                           redDims, d_A, d_map, ws->partials);                                                  \
+    } while (0)
+    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_SELF(3);
+    else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_SELF(6);
+    else DARTK_LAUNCH_SELF(20);
+#undef DARTK_LAUNCH_SELF
+    DARTK_HIP(hipGetLastError());
+    return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
+}
+
+template <int RED>
+static int launch_inter(const float *d_sites, int nSites, int fullDims, int redDims, const float *h_T_ds,
+                        const float *h_T_sd, Model *src, Model *dst, const float *d_A, const int *d_map,
+                        float *d_result, hipStream_t st) {
+    const ModelView &ms = src->v;
+    const ModelView &md = dst->v;
+    DARTK_REQUIRE(fullDims == 6 + ms.nJoints, "dims %d does not match the source model's 6+%d", fullDims, ms.nJoints);
+    const int d = RED ? redDims : fullDims;
+    DARTK_REQUIRE(d >= 6 && d <= kMaxDims, "system dimension %d out of range", d);
+    const int S = sys_size(d);
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    if (nSites == 0) { DARTK_HIP(hipMemsetAsync(d_result, 0, S * sizeof(float), st)); return DARTK_OK; }
+    float hT[24];
+    for (int i = 0; i < 12; ++i) { hT[i] = h_T_ds[i]; hT[12 + i] = h_T_sd[i]; }
+    DARTK_HIP(hipMemcpyAsync(ws->sysScratch + 64, hT, sizeof(hT), hipMemcpyHostToDevice, st));
+    DARTK_HIP(hipStreamSynchronize(st));
+    const int nTiles = (nSites + NE_BLOCK - 1) / NE_BLOCK;
+    const int nBlocks = nTiles < kMaxPartialBlocks ? nTiles : kMaxPartialBlocks;
+    rc = ensure_partials(ws, (size_t)nBlocks * S);
+    if (rc) return rc;
+    size_t words = 24 * (size_t)(ms.nFrames + md.nFrames) + (size_t)NE_BLOCK * row_len(d, false) + 8;
+    if (RED) words += (size_t)NE_BLOCK * (fullDims | 1);
+    const size_t ldsBytes = words * sizeof(float);
+    DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
+#define DARTK_LAUNCH_INTER(PPT_)                                                                                \
+    do {                                                                                                        \
+        auto kfn = ne_intersection_kernel<PPT_, RED>;                                                           \
+        if (ldsBytes > 64 * 1024)                                                                               \
+            DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, ms, md,   \
+                           ws->sysScratch + 64, redDims, d_A, d_map, ws->partials);                             \
+    } while (0)
+    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_INTER(3);
+    else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_INTER(6);
+    else DARTK_LAUNCH_INTER(20);
+#undef DARTK_LAUNCH_INTER
+    DARTK_HIP(hipGetLastError());
+    return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
+}
+
+}  // namespace dartk
+
+using namespace dartk;
+
+extern "C" {
+
+int dartk_ne_self_intersection(const float *d_sites, int nSites, int dims, dartk_model_t h, const int32_t *d_pot,
+                               float *d_result, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(d_sites && d_pot && d_result, "dartk_ne_self_intersection: null argument");
+    int rc = check_sites(mod, nSites);
+    if (rc) return rc;
+    return launch_self<0>(d_sites, nSites, dims, dims, mod, nullptr, nullptr, d_pot, d_result, as_stream(stream));
+}
+int dartk_ne_self_intersection_reduced(const float *d_sites, int nSites, int fullDims, int redDims, dartk_model_t h,
+                                       const float *d_A, const int32_t *d_pot, float *d_result, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(d_sites && d_pot && d_result && d_A, "dartk_ne_self_intersection_reduced: null argument");
+    DARTK_REQUIRE(redDims > 6 && redDims <= fullDims, "redDims %d must be in (6,%d]", redDims, fullDims);
+    int rc = check_sites(mod, nSites);
+    if (rc) return rc;
+    return launch_self<1>(d_sites, nSites, fullDims, redDims, mod, d_A, nullptr, d_pot, d_result, as_stream(stream));
+}
+int dartk_ne_self_intersection_parammap(const float *d_sites, int nSites, int fullDims, int redDims, dartk_model_t h,
+                                        const int32_t *d_map, const int32_t *d_pot, float *d_result, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(d_sites && d_pot && d_result && d_map, "dartk_ne_self_intersection_parammap: null argument");
+    DARTK_REQUIRE(redDims > 6 && redDims <= fullDims, "redDims %d must be in (6,%d]", redDims, fullDims);
+    int rc = check_sites(mod, nSites);
+    if (rc) return rc;
+    return launch_self<2>(d_sites, nSites, fullDims, redDims, mod, nullptr, d_map, d_pot, d_result, as_stream(stream));
+}
+
+int dartk_ne_intersection(const float *d_sites, int nSites, int dims, const float *h_T_ds, const float *h_T_sd,
+                          dartk_model_t hs, dartk_model_t hd, float *d_result, void *stream) {
+    Model *src = reinterpret_cast<Model *>(hs), *dst = reinterpret_cast<Model *>(hd);
+    DARTK_REQUIRE(d_sites && h_T_ds && h_T_sd && src && dst && d_result, "dartk_ne_intersection: null argument");
+    return launch_inter<0>(d_sites, nSites, dims, dims, h_T_ds, h_T_sd, src, dst, nullptr, nullptr, d_result, as_stream(stream));
+}
+int dartk_ne_intersection_reduced(const float *d_sites, int nSites, int fullDims, int redDims, const float *h_T_ds,
+                                  const float *h_T_sd, dartk_model_t hs, dartk_model_t hd, const float *d_A,
+                                  float *d_result, void *stream) {
+    Model *src = reinterpret_cast<Model *>(hs), *dst = reinterpret_cast<Model *>(hd);
+    DARTK_REQUIRE(d_sites && h_T_ds && h_T_sd && src && dst && d_result && d_A, "dartk_ne_intersection_reduced: null argument");
+    DARTK_REQUIRE(redDims >= 6 && redDims <= fullDims, "redDims %d must be in [6,%d]", redDims, fullDims);
+    return launch_inter<1>(d_sites, nSites, fullDims, redDims, h_T_ds, h_T_sd, src, dst, d_A, nullptr, d_result, as_stream(stream));
+}
+int dartk_ne_intersection_parammap(const float *d_sites, int nSites, int fullDims, int redDims, const float *h_T_ds,
+                                   const float *h_T_sd, dartk_model_t hs, dartk_model_t hd, const int32_t *d_map,
+                                   float *d_result, void *stream) {
+    Model *src = reinterpret_cast<Model *>(hs), *dst = reinterpret_cast<Model *>(hd);
+    DARTK_REQUIRE(d_sites && h_T_ds && h_T_sd && src && dst && d_result && d_map, "dartk_ne_intersection_parammap: null argument");
+    DARTK_REQUIRE(redDims >= 6 && redDims <= fullDims, "redDims %d must be in [6,%d]", redDims, fullDims);
+    return launch_inter<2>(d_sites, nSites, fullDims, redDims, h_T_ds, h_T_sd, src, dst, nullptr, d_map, d_result, as_stream(stream));
+}
+
+int dartk_count_self_intersections(const float *d_sites, int nSites, dartk_model_t h, const int32_t *d_pot,
+                                   int32_t *h_count, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(d_sites && d_pot && h_count && mod, "dartk_count_self_intersections: null argument");
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    DARTK_HIP(hipMemsetAsync(ws->counters, 0, sizeof(int), st));
+    if (nSites > 0)
+        hipLaunchKernelGGL(count_self_kernel, dim3((nSites + 127) / 128), dim3(128), 0, st, (const float4 *)d_sites, nSites, mod->v, d_pot, ws->counters);
+    DARTK_HIP(hipGetLastError());
+    DARTK_HIP(hipMemcpyAsync(h_count, ws->counters, sizeof(int), hipMemcpyDeviceToHost, st));
+    DARTK_HIP(hipStreamSynchronize(st));
+    return DARTK_OK;
+}
+
+int dartk_count_intersections(const float *d_sites, int nSites, const float *h_T_ds, dartk_model_t hs, dartk_model_t hd,
+                              int32_t *h_count, void *stream) {
+    Model *src = reinterpret_cast<Model *>(hs), *dst = reinterpret_cast<Model *>(hd);
+    DARTK_REQUIRE(d_sites && h_T_ds && h_count && src && dst, "dartk_count_intersections: null argument");
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    DARTK_HIP(hipMemsetAsync(ws->counters, 0, sizeof(int), st));
+    DARTK_HIP(hipMemcpyAsync(ws->sysScratch + 64, h_T_ds, 12 * sizeof(float), hipMemcpyHostToDevice, st));
+    DARTK_HIP(hipStreamSynchronize(st));
+    if (nSites > 0)
+        hipLaunchKernelGGL(count_inter_kernel, dim3((nSites + 127) / 128), dim3(128), 0, st, (const float4 *)d_sites, nSites, src->v, dst->v, ws->sysScratch + 64, ws->counters);
+    DARTK_HIP(hipGetLastError());
+    DARTK_HIP(hipMemcpyAsync(h_count, ws->counters, sizeof(int), hipMemcpyDeviceToHost, st));
+    DARTK_HIP(hipStreamSynchronize(st));
+    return DARTK_OK;
+}
+
+}  // extern "C"

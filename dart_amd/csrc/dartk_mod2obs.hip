@@ -1,0 +1,514 @@
+// dartk_mod2obs.hip -- SDF ray-cast prediction, observation-SDF construction (splat + distance transform) and
+// the model-to-observation normal equations.
+// Replaces: optimization/kernels/raycast.cu:121-215,440-466; modToObs.cu:14-441,649-709 and wrappers :713-1064;
+//           geometry/distance_transforms.cu:38-126,173-263,434-458,540-562; optimizer.cpp:168-219.
+#include "dartk_internal.h"
+#include "dartk_reduce.h"
+#include "dartk_kernels.h"
+
+namespace dartk {
+
+// -----------------------------------------------------------------------------------------------------
+// ray-cast prediction (raycast.cu:121-215). One lane per prediction pixel; the per-SDF camera<->frame
+// transforms are composed once per workgroup into LDS (lane s does SDF s) instead of once per lane per SDF.
+// -----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+raycast_prediction_kernel(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, ModelView m,
+                          float4 *__restrict__ prediction, float levelSet) {
+    extern __shared__ float lds[];     // [nSdfs][24]: T_fc then T_cf
+    for (int s = threadIdx.x; s < m.nSdfs; s += blockDim.x) {
+        const int f = m.sdfFrame[s];
+        float T_fm[12], T_mf[12], T_mc[12], T_cm[12], T_fc[12], T_cf[12];
+        for (int i = 0; i < 12; ++i) { T_fm[i] = m.T_fm[12 * f + i]; T_mf[i] = m.T_mf[12 * f + i]; T_mc[i] = m.T_mc[i]; }
+        se3_invert(T_mc, T_cm);                 // raycast.cu:143
+        se3_mul(T_fm, T_mc, T_fc);              // T_fms[f]*T_mc
+        se3_mul(T_cm, T_mf, T_cf);              // T_cm*T_mfs[f]
+        for (int i = 0; i < 12; ++i) { lds[24 * s + i] = T_fc[i]; lds[24 * s + 12 + i] = T_cf[i]; }
+    }
+    __syncthreads();
+    // 8x8 pixel tiles, 4 tiles per 256-lane workgroup (tile = wave): neighbouring rays march together
+    const int tilesX = (width + 7) >> 3;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int x = (tile % tilesX) * 8 + (lane & 7);
+    const int y = (tile / tilesX) * 8 + (lane >> 3);
+    if (x >= width || y >= height) return;
+    const int index = x + y * width;
+    float4 pr = prediction[index];
+    if (modelNum == 0) { pr.z = 0; pr.w = -1; }
+
+    const float invflx = 1.0f / flx, invfly = 1.0f / fly;
+    const float uvx = (float)((double)x + 0.5), uvy = (float)((double)y + 0.5);
+    f3 rd; rd.x = (uvx - ppx) * invflx; rd.y = (uvy - ppy) * invfly; rd.z = 1.0f;
+    {
+        const float inv = 1.0f / sqrtf(rd.x * rd.x + rd.y * rd.y + rd.z * rd.z);
+        rd.x *= inv; rd.y *= inv; rd.z *= inv;
+    }
+    float closestT = 10000;
+    for (int s = 0; s < m.nSdfs; ++s) {
+        const SdfDev &sdf = m.sdfs[s];
+        const float *T_fc = lds + 24 * s;
+        const f3 of = se3_apply_w(T_fc, 0.f, 0.f, 0.f, 1.f);
+        const f3 df = se3_apply_w(T_fc, rd.x, rd.y, rd.z, 0.f);
+        f3 dn;
+        {
+            const float inv = 1.0f / sqrtf(df.x * df.x + df.y * df.y + df.z * df.z);
+            dn.x = df.x * inv; dn.y = df.y * inv; dn.z = df.z * inv;
+        }
+        const float sminx = sdf.ox, sminy = sdf.oy, sminz = sdf.oz;
+        const float smaxx = sdf.ox + sdf.res * (float)(unsigned)sdf.dimx;
+        const float smaxy = sdf.oy + sdf.res * (float)(unsigned)sdf.dimy;
+        const float smaxz = sdf.oz + sdf.res * (float)(unsigned)sdf.dimz;
+        const float hix = (float)((unsigned)sdf.dimx - 2u), hiy = (float)((unsigned)sdf.dimy - 2u), hiz = (float)((unsigned)sdf.dimz - 2u);
+        // intersectBox, raycast.cu:11-35
+        float t0, t1;
+        {
+            const float ix = 1.0f / dn.x, iy = 1.0f / dn.y, iz = 1.0f / dn.z;
+            const float bx = ix * (sminx - of.x), by = iy * (sminy - of.y), bz = iz * (sminz - of.z);
+            const float tx = ix * (smaxx - of.x), ty = iy * (smaxy - of.y), tz = iz * (smaxz - of.z);
+            const float mnx = fminf(tx, bx), mny = fminf(ty, by), mnz = fminf(tz, bz);
+            const float mxx = fmaxf(tx, bx), mxy = fmaxf(ty, by), mxz = fmaxf(tz, bz);
+            t0 = fmaxf(fmaxf(mnx, mny), mnz);
+            t1 = fminf(fminf(mxx, mxy), mxz);
+        }
+        if (!(t1 > t0)) continue;
+        const float *data = m.grids + sdf.dataOff;
+        auto eval = [&](float tt) -> float {
+            f3 xf, xg;
+            xf.x = dn.x * tt + of.x; xf.y = dn.y * tt + of.y; xf.z = dn.z * tt + of.z;
+            xg.x = fmaxf(1.0f, fminf((xf.x - sdf.ox) / sdf.res, hix));
+            xg.y = fmaxf(1.0f, fminf((xf.y - sdf.oy) / sdf.res, hiy));
+            xg.z = fmaxf(1.0f, fminf((xf.z - sdf.oz) / sdf.res, hiz));
+            return grid_value(data, sdf.dimx, sdf.dimy, xg) * sdf.res;
+        };
+        float sdfVal = eval(t0);
+        float sdfValPrev = sdfVal;
+        float tPrev = t0;
+        const float minStep = sdf.res / 10;
+        while (t0 < t1 && t0 < closestT) {
+            sdfVal = eval(t0);
+            if (sdfValPrev > levelSet && sdfVal <= levelSet) {
+                const float tHit = (t0 - tPrev) * (levelSet - sdfValPrev) / (sdfVal - sdfValPrev) + tPrev;
+                const f3 xc = se3_apply_w(lds + 24 * s + 12, dn.x * tHit + of.x, dn.y * tHit + of.y, dn.z * tHit + of.z, 1.0f);
+                if (pr.z == 0 || xc.z < pr.z) {
+                    pr.x = xc.x; pr.y = xc.y; pr.z = xc.z; pr.w = (float)((modelNum << 16) + s);
+                }
+                closestT = tHit;
+            }
+            sdfValPrev = sdfVal;
+            tPrev = t0;
+            t0 += fmaxf(minStep, fabsf(sdfVal));
+        }
+    }
+    prediction[index] = pr;
+}
+
+// gpu_cullUnobservable, modToObs.cu:682-709
+__global__ void cull_unobservable_kernel(float4 *__restrict__ pred, int pw, int ph, const float4 *__restrict__ obs, int ow, int oh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pw * ph) return;
+    const int px = i % pw, py = i / pw;
+    const int ox = px * ow / pw, oy = py * oh / ph;
+    const int oi = ox + oy * ow;
+    if (obs[oi].w <= 0 || obs[oi + 1].w <= 0 || obs[oi + ow].w <= 0 || obs[oi + ow + 1].w <= 0) pred[i].z = 0;
+}
+
+// gpu_splatObsSdf, modToObs.cu:403-441
+__global__ void splat_obs_sdf_kernel(const float4 *__restrict__ vert, int width, int height, ModelView m, float focalLength) {
+    const int nVox = m.obs.dimx * m.obs.dimy * m.obs.dimz;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nVox) return;
+    const int x = i % m.obs.dimx, y = (i / m.obs.dimx) % m.obs.dimy, z = i / (m.obs.dimx * m.obs.dimy);
+    const float *__restrict__ T_cm = m.T_cm;
+    f3 p; p.x = m.obs.ox + m.obs.res * (float)x; p.y = m.obs.oy + m.obs.res * (float)y; p.z = m.obs.oz + m.obs.res * (float)z;
+    const f3 c = se3_apply(T_cm, p);
+    const int u = (int)roundf((focalLength / c.z) * c.x + (float)(width >> 1));
+    const int v = (int)roundf((focalLength / c.z) * c.y + (float)(height >> 1));
+    float val;
+    if (u < 0 || u >= width || v < 0 || v >= height) val = 1000.0f;
+    else {
+        const float4 o = vert[u + v * width];
+        if (o.w == 0 || o.z == 0) val = 500.0f;
+        else if (o.z < c.z) val = 0.0f;
+        else val = 1000.0f;
+    }
+    m.obsData[i] = val;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// distance transform. The reference runs Felzenszwalb's serial lower-envelope scan with one thread per grid
+// line (distance_transforms.cu:38-126). On a 64-lane machine with 160 KB of LDS the direct min-plus form
+//     out[q] = min_p ( (q-p)^2 + in[p] )
+// is both parallel over q and cheap (len <= 512): one lane per output voxel, the line resident in LDS. For the
+// integer-valued inputs these transforms see (0 / 500 / 1000 / 1e20 and squared integer distances, all exact
+// in fp32) the minimum is exact, i.e. identical to what the envelope scan returns.
+// -----------------------------------------------------------------------------------------------------
+// along x (stride 1): one workgroup per group of lines
+__global__ void __launch_bounds__(256)
+dt_pass_x_kernel(const float *__restrict__ in, float *__restrict__ out, int len, int nLines, int takeSqrt) {
+    extern __shared__ float lds[];
+    const int linesPerBlock = max(1, 256 / len);
+    const int line0 = blockIdx.x * linesPerBlock;
+    const int nl = min(linesPerBlock, nLines - line0);
+    const int total = nl * len;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) lds[i] = in[(size_t)line0 * len + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int l = i / len, q = i - l * len;
+        const float *row = lds + l * len;
+        float best = 3.0e38f;
+        for (int p = 0; p < len; ++p) {
+            const int d = q - p;
+            best = fminf(best, (float)(d * d) + row[p]);
+        }
+        out[(size_t)line0 * len + i] = takeSqrt ? sqrtf(best) : best;
+    }
+}
+// along a strided axis: workgroup = 64 consecutive x by the whole line; lanes (x, q-group)
+__global__ void __launch_bounds__(256)
+dt_pass_strided_kernel(const float *__restrict__ in, float *__restrict__ out, int len, int stride, int width, int nOuter,
+                       int outerStride, int takeSqrt) {
+    extern __shared__ float lds[];      // [len][64]
+    const int tilesX = (width + 63) / 64;
+    const int x0 = (blockIdx.x % tilesX) * 64;
+    const int outer = blockIdx.x / tilesX;
+    if (outer >= nOuter) return;
+    const int lx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t base = (size_t)outer * outerStride + x0 + lx;
+    const bool ok = (x0 + lx) < width;
+    for (int p = g; p < len; p += 4) lds[p * 64 + lx] = ok ? in[base + (size_t)p * stride] : 3.0e38f;
+    __syncthreads();
+    if (!ok) return;
+    for (int q = g; q < len; q += 4) {
+        float best = 3.0e38f;
+        for (int p = 0; p < len; ++p) {
+            const int d = q - p;
+            best = fminf(best, (float)(d * d) + lds[p * 64 + lx]);
+        }
+        out[base + (size_t)q * stride] = takeSqrt ? sqrtf(best) : best;
+    }
+}
+
+int launch_distance_transform_3d(float *in, float *out, int width, int height, int depth, int takeSqrt, hipStream_t st) {
+    DARTK_REQUIRE(width >= 1 && height >= 1 && depth >= 1 && width <= 512 && height <= 512 && depth <= 512,
+                  "distance transform dimensions must be in [1,512], got %dx%dx%d", width, height, depth);
+    // x: in -> out ; z: out -> in ; y: in -> out (sqrt)   (distance_transforms.cu:440-456)
+    {
+        const int nLines = height * depth;
+        const int lpb = 256 / width > 0 ? 256 / width : 1;
+        hipLaunchKernelGGL(dt_pass_x_kernel, dim3((nLines + lpb - 1) / lpb), dim3(256), sizeof(float) * (size_t)(lpb * width), st,
+                           in, out, width, nLines, 0);
+    }
+    const int tilesX = (width + 63) / 64;
+    hipLaunchKernelGGL(dt_pass_strided_kernel, dim3(tilesX * height), dim3(256), sizeof(float) * 64 * (size_t)depth, st,
+                       out, in, depth, width * height, width, height, width, 0);
+    hipLaunchKernelGGL(dt_pass_strided_kernel, dim3(tilesX * depth), dim3(256), sizeof(float) * 64 * (size_t)height, st,
+                       in, out, height, width, width, depth, width * height, takeSqrt);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
+// gpu_seedInverseTransform3D (distance_transforms.cu:173-227) / gpu_combineTransforms3D (:248-263)
+__global__ void dt_seed_kernel(const float *__restrict__ im, float *__restrict__ seed, int w, int h, int d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * h * d) return;
+    const int x = i % w, y = (i / w) % h, z = i / (w * h);
+    float s = 0.0f;
+    if (im[i] == 0) {
+        s = 1e20f;
+        if ((x > 0 && im[i - 1] != 0.0f) || (x < w - 1 && im[i + 1] != 0.0f) || (y > 0 && im[i - w] != 0.0f) ||
+            (y < h - 1 && im[i + w] != 0.0f) || (z > 0 && im[i - w * h] != 0.0f) || (z < d - 1 && im[i + w * h] != 0.0f))
+            s = 0.0f;
+    }
+    seed[i] = s;
+}
+__global__ void dt_combine_kernel(float *__restrict__ im, const float *__restrict__ neg, const float *__restrict__ mask, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && mask[i] == 0) im[i] = -neg[i];
+}
+
+// -----------------------------------------------------------------------------------------------------
+// mod -> obs normal equations (modToObs.cu:14-401). One lane per prediction pixel; pixels that contribute
+// are compacted (deterministically) into LDS rows before the pair reduction, so empty image regions cost one
+// ballot. RED: 0 full, 1 linear, 2 param map. TRUNC: truncation window (modToObs.cu:163-166).
+// -----------------------------------------------------------------------------------------------------
+template <int PPT, int RED, bool TRUNC>
+__global__ void __launch_bounds__(NE_BLOCK)
+ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, ModelView m, const float *__restrict__ T_gc_in,
+                  float truncationDist, int redDims, const float *__restrict__ dtheta_dalpha, const int *__restrict__ mapping,
+                  float *__restrict__ slabs, int *__restrict__ numPredictions) {
+    extern __shared__ float lds[];
+    const int fullDims = 6 + m.nJoints;
+    const int d = RED ? redDims : fullDims;
+    const int ld = row_len(d, false);
+    float *sT_fm = lds;
+    float *sT_mf = sT_fm + 12 * m.nFrames;
+    const int fullLd = fullDims | 1;
+    float *sFull = sT_mf + 12 * m.nFrames;
+    float *rows = sFull + (RED ? NE_BLOCK * fullLd : 0);
+    int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ld);
+    stage_model(m, sT_fm, sT_mf, nullptr);
+    float T_gc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T_gc[i] = T_gc_in[i];
+    const SdfDev obs = m.obs;
+    const float *__restrict__ obsData = m.obsData;
+
+    PairAcc<NE_BLOCK, PPT> acc;
+    acc.init(d, false);
+    int myCount = 0;
+    const int nTiles = (nPix + NE_BLOCK - 1) / NE_BLOCK;
+    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        const int index = tile * NE_BLOCK + threadIdx.x;
+        bool active = false;
+        f3 pm, pg;
+        float residual = 0.0f;
+        int frame = 0;
+        if (index < nPix) {
+            const float4 pc = pred[index];
+            if (pc.z != 0) {
+                f3 p3; p3.x = pc.x; p3.y = pc.y; p3.z = pc.z;
+                pm = se3_apply(T_gc, p3);
+                pg = grid_coords(obs, pm);
+                if (in_bounds_grad_interp(obs, pg)) {
+                    residual = grid_value(obsData, obs.dimx, obs.dimy, pg) * obs.res;
+                    bool ok = true;
+                    if (TRUNC) ok = !(residual >= truncationDist || residual < 0);
+                    if (ok) {
+                        const int label = (int)roundf(pc.w);
+                        if ((label >> 16) == modelNum) {
+                            frame = m.sdfFrame[label & 65535];
+                            active = true;
+                        }
+                    }
+                }
+            }
+        }
+        int nActive;
+        const int slot = compact_slot<NE_BLOCK>(active, waveCnt, nActive);
+        if (active) {
+            float *row = rows + slot * ld;
+            const f3 gm = grid_gradient(obsData, obs.dimx, obs.dimy, pg);
+            float *Jfull = RED ? (sFull + threadIdx.x * fullLd) : row;
+            error_jacobian<false>(Jfull, pm, 1.0f, m.depMask[frame], gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
+            if (RED) reduce_jacobian<RED>(row, Jfull, 6, fullDims, redDims, dtheta_dalpha, mapping);
+            row[d] = residual;
+            row[d + 1] = (float)(0.5 * (double)residual * (double)residual);
+            row[d + 2] = 1.0f;
+        }
+        __syncthreads();
+        if (nActive) acc.accumulate(rows, ld, nActive);
+        myCount += nActive;
+        __syncthreads();
+    }
+    acc.store(slabs + (size_t)blockIdx.x * sys_size(d), sys_size(d));
+    if (threadIdx.x == 0 && myCount) atomicAdd(numPredictions, myCount);
+}
+
+size_t ne_mod2obs_lds_bytes(const ModelView &m, int d, int red) {
+    const int fullDims = 6 + m.nJoints;
+    size_t words = 24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8;
+    if (red) words += (size_t)NE_BLOCK * (fullDims | 1);
+    return words * sizeof(float);
+}
+
+template <int RED, bool TRUNC>
+static int launch_ne_mod2obs(int fullDims, int redDims, const float *d_pred, int width, int height, Model *mod,
+                             const float *d_T_gc, float trunc, const float *d_A, const int *d_map, float *d_result,
+                             int *d_num, bool zeroCounter, hipStream_t st) {
+    const ModelView &m = mod->v;
+    const int d = RED ? redDims : fullDims;
+    DARTK_REQUIRE(fullDims == 6 + m.nJoints, "dims %d does not match the model's 6+%d", fullDims, m.nJoints);
+    DARTK_REQUIRE(d >= 6 && d <= kMaxDims, "system dimension %d out of range [6,%d]", d, kMaxDims);
+    DARTK_REQUIRE(width > 0 && height > 0, "bad prediction size %dx%d", width, height);
+    DARTK_REQUIRE(mod->obsVoxels > 0, "model has no observation SDF");
+    const int S = sys_size(d);
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    const int nPix = width * height;
+    const int nTiles = (nPix + NE_BLOCK - 1) / NE_BLOCK;
+    const int nBlocks = nTiles < kMaxPartialBlocks ? nTiles : kMaxPartialBlocks;
+    rc = ensure_partials(ws, (size_t)nBlocks * S);
+    if (rc) return rc;
+    if (zeroCounter) DARTK_HIP(hipMemsetAsync(d_num, 0, sizeof(int), st));
+    const size_t ldsBytes = ne_mod2obs_lds_bytes(m, d, RED);
+    DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
+    const float4 *pred = reinterpret_cast<const float4 *>(d_pred);
+#define DARTK_LAUNCH_M2O(PPT_)                                                                                  \
+    do {                                                                                                        \
+        auto kfn = ne_mod2obs_kernel<PPT_, RED, TRUNC>;                                                         \
+        if (ldsBytes > 64 * 1024)                                                                               \
+            DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, pred, nPix, m.modelId, m, d_T_gc, trunc,     \
+                           redDims, d_A, d_map, ws->partials, d_num);                                           \
+    } while (0)
+    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_M2O(3);
+    else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_M2O(6);
+    else DARTK_LAUNCH_M2O(20);
+#undef DARTK_LAUNCH_M2O
+    DARTK_HIP(hipGetLastError());
+    return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
+}
+
+// gpu_errorModToObs, modToObs.cu:649-680 (prediction used in camera coordinates, as the reference does)
+__global__ void __launch_bounds__(256)
+error_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, ModelView m, double *__restrict__ blockSums) {
+    __shared__ double red[256];
+    const SdfDev obs = m.obs;
+    double s = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nPix; i += gridDim.x * blockDim.x) {
+        const float4 pv = pred[i];
+        if (pv.z == 0) continue;
+        f3 p; p.x = pv.x; p.y = pv.y; p.z = pv.z;
+        const f3 pg = grid_coords(obs, p);
+        if (!in_bounds_grad_interp(obs, pg)) continue;
+        const float err = grid_value(m.obsData, obs.dimx, obs.dimy, pg) * obs.res;
+        s += (double)(float)(0.5 * (double)err * (double)err);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = red[0];
+}
+
+}  // namespace dartk
+
+using namespace dartk;
+
+extern "C" {
+
+int dartk_raycast_prediction(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum,
+                             dartk_model_t h, float *d_prediction, float levelSet, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_prediction, "dartk_raycast_prediction: null argument");
+    DARTK_REQUIRE(width > 0 && height > 0 && flx != 0 && fly != 0, "bad camera %dx%d f=(%g,%g)", width, height, flx, fly);
+    DARTK_REQUIRE(modelNum >= 0 && modelNum < 32768, "modelNum %d out of range", modelNum);
+    const int tiles = ((width + 7) / 8) * ((height + 7) / 8);
+    hipLaunchKernelGGL(raycast_prediction_kernel, dim3((tiles + 3) / 4), dim3(256), sizeof(float) * 24 * (size_t)mod->v.nSdfs,
+                       as_stream(stream), flx, fly, ppx, ppy, width, height, modelNum, mod->v, (float4 *)d_prediction, levelSet);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
+int dartk_cull_unobservable(float *d_pred, int pw, int ph, const float *d_obs, int ow, int oh, void *stream) {
+    DARTK_REQUIRE(d_pred && d_obs && pw > 0 && ph > 0 && ow > 1 && oh > 1, "dartk_cull_unobservable: bad argument");
+    // the 2x2 neighbourhood read at (ox+1, oy+1) must stay inside the observation map
+    DARTK_REQUIRE((long long)(pw - 1) * ow / pw + 1 < ow && (long long)(ph - 1) * oh / ph + 1 < oh,
+                  "prediction %dx%d must be at most half the observation %dx%d resolution", pw, ph, ow, oh);
+    hipLaunchKernelGGL(cull_unobservable_kernel, dim3((pw * ph + 255) / 256), dim3(256), 0, as_stream(stream),
+                       (float4 *)d_pred, pw, ph, (const float4 *)d_obs, ow, oh);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
+int dartk_distance_transform_3d(float *d_in, float *d_out, int width, int height, int depth, int takeSqrt, void *stream) {
+    DARTK_REQUIRE(d_in && d_out && d_in != d_out, "dartk_distance_transform_3d: bad buffers");
+    return launch_distance_transform_3d(d_in, d_out, width, height, depth, takeSqrt, as_stream(stream));
+}
+
+int dartk_signed_distance_transform_3d(float *d_in, float *d_out, int width, int height, int depth, int takeSqrt, void *stream) {
+    DARTK_REQUIRE(d_in && d_out && d_in != d_out, "dartk_signed_distance_transform_3d: bad buffers");
+    DARTK_REQUIRE(width >= 1 && height >= 1 && depth >= 1, "bad dimensions");
+    hipStream_t st = as_stream(stream);
+    const int n = width * height * depth;
+    float *seedDT = nullptr;
+    DARTK_HIP(hipMalloc((void **)&seedDT, sizeof(float) * (size_t)n));   // cold path (model load), like the reference (:532)
+    float *seed = d_out;
+    hipLaunchKernelGGL(dt_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_in, seed, width, height, depth);
+    int rc = launch_distance_transform_3d(seed, seedDT, width, height, depth, takeSqrt, st);
+    if (!rc) rc = launch_distance_transform_3d(d_in, d_out, width, height, depth, takeSqrt, st);
+    if (!rc) hipLaunchKernelGGL(dt_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_out, seedDT, d_in, n);
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(seedDT);
+    if (rc) return rc;
+    DARTK_HIP(e);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
+int dartk_obs_sdf_build(const float *d_vert, int width, int height, dartk_model_t h, float focalLength, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_vert, "dartk_obs_sdf_build: null argument");
+    DARTK_REQUIRE(mod->obsVoxels > 0, "model has no observation SDF");
+    DARTK_REQUIRE(width > 0 && height > 0, "bad map size");
+    hipStream_t st = as_stream(stream);
+    const ModelView &m = mod->v;
+    const int n = (int)mod->obsVoxels;
+    hipLaunchKernelGGL(splat_obs_sdf_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float4 *)d_vert, width, height, m, focalLength);
+    DARTK_HIP(hipGetLastError());
+    int rc = launch_distance_transform_3d(m.obsData, mod->dtTmp, m.obs.dimx, m.obs.dimy, m.obs.dimz, 1, st);
+    if (rc) return rc;
+    DARTK_HIP(hipMemcpyAsync(m.obsData, mod->dtTmp, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, st));  // optimizer.cpp:215
+    return DARTK_OK;
+}
+
+static int upload_T(const float *h_T, float **d_T, hipStream_t st) {
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    // staged through the workspace scratch; synchronous (12 floats) so the host array may be a temporary
+    DARTK_HIP(hipMemcpyAsync(ws->sysScratch, h_T, 12 * sizeof(float), hipMemcpyHostToDevice, st));
+    DARTK_HIP(hipStreamSynchronize(st));
+    *d_T = ws->sysScratch;
+    return DARTK_OK;
+}
+
+int dartk_ne_mod2obs(int dims, const float *d_pred, int width, int height, dartk_model_t h, const float *h_T_gc,
+                     float *d_result, int32_t *d_num, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_pred && h_T_gc && d_result && d_num, "dartk_ne_mod2obs: null argument");
+    float *d_T = nullptr;
+    int rc = upload_T(h_T_gc, &d_T, as_stream(stream));
+    if (rc) return rc;
+    return launch_ne_mod2obs<0, false>(dims, dims, d_pred, width, height, mod, d_T, 0.f, nullptr, nullptr, d_result, d_num, true, as_stream(stream));
+}
+
+int dartk_ne_mod2obs_truncated(int dims, const float *d_pred, int width, int height, dartk_model_t h, float trunc,
+                               float *d_result, int32_t *d_num, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_pred && d_result && d_num, "dartk_ne_mod2obs_truncated: null argument");
+    return launch_ne_mod2obs<0, true>(dims, dims, d_pred, width, height, mod, mod->v.T_mc, trunc, nullptr, nullptr, d_result, d_num, true, as_stream(stream));
+}
+
+int dartk_ne_mod2obs_reduced(int dims, int redDims, const float *d_A, const float *d_pred, int width, int height,
+                             dartk_model_t h, float *d_result, int32_t *d_num, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_pred && d_result && d_num && d_A, "dartk_ne_mod2obs_reduced: null argument");
+    DARTK_REQUIRE(redDims >= 6 && redDims <= dims, "redDims %d must be in [6,%d]", redDims, dims);
+    return launch_ne_mod2obs<1, false>(dims, redDims, d_pred, width, height, mod, mod->v.T_mc, 0.f, d_A, nullptr, d_result, d_num, false, as_stream(stream));
+}
+
+int dartk_ne_mod2obs_parammap(int dims, int redDims, const int32_t *d_map, const float *d_pred, int width, int height,
+                              dartk_model_t h, float *d_result, int32_t *d_num, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_pred && d_result && d_num && d_map, "dartk_ne_mod2obs_parammap: null argument");
+    DARTK_REQUIRE(redDims >= 6 && redDims <= dims, "redDims %d must be in [6,%d]", redDims, dims);
+    return launch_ne_mod2obs<2, false>(dims, redDims, d_pred, width, height, mod, mod->v.T_mc, 0.f, nullptr, d_map, d_result, d_num, false, as_stream(stream));
+}
+
+int dartk_error_mod2obs(const float *d_pred, int width, int height, dartk_model_t h, float *h_error, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_pred && h_error, "dartk_error_mod2obs: null argument");
+    DARTK_REQUIRE(mod->obsVoxels > 0, "model has no observation SDF");
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    const int nBlocks = 64;
+    double *sums = reinterpret_cast<double *>(ws->partials);
+    hipLaunchKernelGGL(error_mod2obs_kernel, dim3(nBlocks), dim3(256), 0, st, (const float4 *)d_pred, width * height, mod->v, sums);
+    DARTK_HIP(hipGetLastError());
+    double hs[64];
+    DARTK_HIP(hipMemcpyAsync(hs, sums, sizeof(hs), hipMemcpyDeviceToHost, st));
+    DARTK_HIP(hipStreamSynchronize(st));
+    double s = 0;
+    for (int i = 0; i < nBlocks; ++i) s += hs[i];
+    *h_error = (float)s;
+    return DARTK_OK;
+}
+
+}  // extern "C"

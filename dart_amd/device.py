@@ -98,6 +98,8 @@ def pts_to_numpy(pts, count):
 
 
 def pts_from_numpy(rec, device="cuda"):
+    if len(rec) == 0:
+        return new_pts(1, device)
     raw = np.empty((len(rec), 3), dtype=np.int32)
     raw[:, 0] = rec["index"]
     raw[:, 1] = rec["dataAssociation"]
@@ -170,3 +172,133 @@ def norm_eqns_obs_to_mod(vert, model, pts, n_elements, huber_delta=0.02, reducti
         check(lib().dartk_ne_obs2mod_parammap(dims, rd, _ptr(reduction[1]), _ptr(vert), w, h, model.handle, huber_delta,
                                               _ptr(pts), n_elements, _ptr(result), _stream()))
     return result
+
+
+# ---------------------------------------------------------------------------------------------- mod -> obs
+def raycast_prediction(models, focal_length, principal_point, width, height, prediction=None, level_set=0.0):
+    """PredictionRenderer::raytracePrediction (prediction_renderer.cpp:193-217): one launch per model, model m
+    is rendered with modelNum = m (model 0 clears the map). Returns the float4 [H,W,4] prediction."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if prediction is None:
+        prediction = torch.zeros((height, width, 4), dtype=torch.float32, device=dev)
+    for num, m in enumerate(models):
+        check(lib().dartk_raycast_prediction(focal_length[0], focal_length[1], principal_point[0], principal_point[1], width,
+                                             height, num, m.handle, _ptr(prediction), level_set, _stream()))
+    return prediction
+
+
+def cull_unobservable(prediction, obs_vert):
+    ph, pw = prediction.shape[:2]
+    oh, ow = obs_vert.shape[:2]
+    check(lib().dartk_cull_unobservable(_ptr(prediction), pw, ph, _ptr(obs_vert), ow, oh, _stream()))
+    return prediction
+
+
+def generate_obs_sdf(vert, model, focal_length=537.0):
+    """Optimizer::generateObsSdf (optimizer.cpp:159-219) using the model's current pose."""
+    h, w = vert.shape[:2]
+    check(lib().dartk_obs_sdf_build(_ptr(vert), w, h, model.handle, focal_length, _stream()))
+
+
+def obs_sdf_numpy(model):
+    """Host copy [D,H,W] of the model's observation SDF (MirroredModel::getObsSdf after a device->host sync)."""
+    dim = model.obs_layout[0]
+    out = np.empty((dim[2], dim[1], dim[0]), dtype=F)
+    ptr = lib().dartk_model_obs_sdf_data(model.handle)
+    check(lib().dartk_buf_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, _stream()))
+    return out
+
+
+def set_obs_sdf(model, data):
+    """Upload observation-SDF voxel data (MirroredModel::syncObsSdfHostToDevice)."""
+    dim = model.obs_layout[0]
+    data = np.ascontiguousarray(data, dtype=F)
+    assert data.size == dim[0] * dim[1] * dim[2]
+    ptr = lib().dartk_model_obs_sdf_data(model.handle)
+    check(lib().dartk_buf_h2d(C.c_void_p(ptr), data.ctypes.data_as(C.c_void_p), data.nbytes, _stream()))
+
+
+def distance_transform_3d(grid_in, take_sqrt=True, signed=False):
+    """distanceTransform3D / signedDistanceTransform3D (distance_transforms.h:16-29). grid_in: CUDA float tensor
+    [D,H,W]; it is clobbered like the reference's input. Returns the output tensor."""
+    d, h, w = grid_in.shape
+    out = torch.empty_like(grid_in)
+    fn = lib().dartk_signed_distance_transform_3d if signed else lib().dartk_distance_transform_3d
+    check(fn(_ptr(grid_in), _ptr(out), w, h, d, int(take_sqrt), _stream()))
+    return out
+
+
+def norm_eqns_mod_to_obs(prediction, model, T_gc=None, truncation=None, reduction=None, result=None, counter=None):
+    """normEqnsModToObs{,Truncated,Reduced,ParamMap} (modToObs.h:13-90). Returns (packed system, counter tensor)."""
+    h, w = prediction.shape[:2]
+    dims = model.dims
+    rd = dims if reduction is None else reduction[2]
+    if result is None:
+        result = torch.empty(sys_len(rd), dtype=torch.float32, device=prediction.device)
+    if counter is None:
+        counter = torch.zeros(1, dtype=torch.int32, device=prediction.device)
+    if reduction is None and truncation is None:
+        T = np.ascontiguousarray(T_gc, dtype=F).reshape(12)
+        check(lib().dartk_ne_mod2obs(dims, _ptr(prediction), w, h, model.handle, _abi.fptr(T), _ptr(result), _ptr(counter), _stream()))
+    elif reduction is None:
+        check(lib().dartk_ne_mod2obs_truncated(dims, _ptr(prediction), w, h, model.handle, truncation, _ptr(result), _ptr(counter), _stream()))
+    elif reduction[0] == "linear":
+        check(lib().dartk_ne_mod2obs_reduced(dims, rd, _ptr(reduction[1]), _ptr(prediction), w, h, model.handle, _ptr(result), _ptr(counter), _stream()))
+    else:
+        check(lib().dartk_ne_mod2obs_parammap(dims, rd, _ptr(reduction[1]), _ptr(prediction), w, h, model.handle, _ptr(result), _ptr(counter), _stream()))
+    return result, counter
+
+
+def error_mod_to_obs(prediction, model):
+    h, w = prediction.shape[:2]
+    e = np.zeros(1, dtype=F)
+    check(lib().dartk_error_mod2obs(_ptr(prediction), w, h, model.handle, _abi.fptr(e), _stream()))
+    return float(e[0])
+
+
+# ---------------------------------------------------------------------------------------------- intersection
+def norm_eqns_self_intersection(sites, model, potential, reduction=None, result=None):
+    """normEqnsSelfIntersection{,Reduced,ParamMap} (intersection.h). sites: CUDA [N,4]; potential: int32 [nSdfs^2]."""
+    n = sites.shape[0]
+    dims = model.dims
+    rd = dims if reduction is None else reduction[2]
+    if result is None:
+        result = torch.empty(sys_len(rd - 6), dtype=torch.float32, device=sites.device)
+    if reduction is None:
+        check(lib().dartk_ne_self_intersection(_ptr(sites), n, dims, model.handle, _ptr(potential), _ptr(result), _stream()))
+    elif reduction[0] == "linear":
+        check(lib().dartk_ne_self_intersection_reduced(_ptr(sites), n, dims, rd, model.handle, _ptr(reduction[1]), _ptr(potential), _ptr(result), _stream()))
+    else:
+        check(lib().dartk_ne_self_intersection_parammap(_ptr(sites), n, dims, rd, model.handle, _ptr(reduction[1]), _ptr(potential), _ptr(result), _stream()))
+    return result
+
+
+def norm_eqns_intersection(sites, src, dst, T_ds, T_sd, reduction=None, result=None):
+    """normEqnsIntersection{,Reduced,ParamMap} (intersection.h)."""
+    n = sites.shape[0]
+    dims = src.dims
+    rd = dims if reduction is None else reduction[2]
+    if result is None:
+        result = torch.empty(sys_len(rd), dtype=torch.float32, device=sites.device)
+    a = np.ascontiguousarray(T_ds, dtype=F).reshape(12)
+    b = np.ascontiguousarray(T_sd, dtype=F).reshape(12)
+    if reduction is None:
+        check(lib().dartk_ne_intersection(_ptr(sites), n, dims, _abi.fptr(a), _abi.fptr(b), src.handle, dst.handle, _ptr(result), _stream()))
+    elif reduction[0] == "linear":
+        check(lib().dartk_ne_intersection_reduced(_ptr(sites), n, dims, rd, _abi.fptr(a), _abi.fptr(b), src.handle, dst.handle, _ptr(reduction[1]), _ptr(result), _stream()))
+    else:
+        check(lib().dartk_ne_intersection_parammap(_ptr(sites), n, dims, rd, _abi.fptr(a), _abi.fptr(b), src.handle, dst.handle, _ptr(reduction[1]), _ptr(result), _stream()))
+    return result
+
+
+def count_self_intersections(sites, model, potential):
+    c = np.zeros(1, dtype=np.int32)
+    check(lib().dartk_count_self_intersections(_ptr(sites), sites.shape[0], model.handle, _ptr(potential), _abi.iptr(c), _stream()))
+    return int(c[0])
+
+
+def count_intersections(sites, src, dst, T_ds):
+    c = np.zeros(1, dtype=np.int32)
+    a = np.ascontiguousarray(T_ds, dtype=F).reshape(12)
+    check(lib().dartk_count_intersections(_ptr(sites), sites.shape[0], _abi.fptr(a), src.handle, dst.handle, _abi.iptr(c), _stream()))
+    return int(c[0])

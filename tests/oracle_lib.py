@@ -192,3 +192,80 @@ def model_jacobian_3d(om, T_fm, T_mf, point_m, frame):
     p4 = c32(list(point_m[:3]) + [1.0])
     lib().orc_model_jacobian_3d(om.ref, f(c32(T_fm)), f(c32(T_mf)), f(p4), int(frame), f(J))
     return J
+
+
+# ---------------------------------------------------------------------------------------------- mod -> obs
+def raycast_prediction(oms, poses, fl, pp, width, height, level_set=0.0):
+    """poses: list of (T_mc, T_fm, T_mf) per model; returns [H,W,4]."""
+    pred = np.zeros((height, width, 4), dtype=F)
+    for num, (om, (T_mc, T_fm, T_mf)) in enumerate(zip(oms, poses)):
+        lib().orc_raycast_prediction(C.c_float(fl[0]), C.c_float(fl[1]), C.c_float(pp[0]), C.c_float(pp[1]), width, height, num,
+                                     om.ref, f(c32(T_mc)), f(c32(T_fm)), f(c32(T_mf)), C.c_float(level_set), f(pred))
+    return pred
+
+
+def cull_unobservable(pred, obs):
+    pred = c32(pred).copy()
+    lib().orc_cull_unobservable(f(pred), pred.shape[1], pred.shape[0], f(c32(obs)), obs.shape[1], obs.shape[0])
+    return pred
+
+
+def splat_obs_sdf(vert, T_cm, obs_layout, focal_length=537.0):
+    dim, off, res = obs_layout
+    data = np.zeros((dim[2], dim[1], dim[0]), dtype=F)
+    g = make_grid(dim, off, res, data)
+    lib().orc_splat_obs_sdf(f(c32(vert)), vert.shape[1], vert.shape[0], f(c32(T_cm)), C.byref(g), C.c_float(focal_length), f(data))
+    return data
+
+
+def distance_transform_3d(grid, take_sqrt=True, signed=False):
+    a = c32(grid).copy()
+    out = np.zeros_like(a)
+    d, h, w = a.shape
+    fn = lib().orc_signed_distance_transform_3d if signed else lib().orc_distance_transform_3d
+    fn(f(a), f(out), w, h, d, int(take_sqrt))
+    return out
+
+
+def ne_mod2obs(pred, om, T_gc, T_fm, T_mf, obs_grid, truncation=None, reduction=None):
+    red, rd, A, mp, keep = _red_args(reduction)
+    d = rd if red else om.dims
+    res = np.zeros(sys_len(d), dtype=F)
+    lib().orc_ne_mod2obs.restype = C.c_int
+    n = lib().orc_ne_mod2obs(f(c32(pred)), pred.shape[1], pred.shape[0], om.model_id, om.ref, f(c32(T_gc)), f(c32(T_fm)), f(c32(T_mf)),
+                             C.byref(obs_grid), C.c_float(-1.0 if truncation is None else truncation), red, rd, A, mp, f(res))
+    return res, n
+
+
+def error_mod2obs(pred, obs_grid):
+    return float(lib().orc_error_mod2obs(f(c32(pred)), pred.shape[1], pred.shape[0], C.byref(obs_grid)))
+
+
+# ---------------------------------------------------------------------------------------------- intersection
+def ne_self_intersection(sites, om, T_fm, T_mf, pot, reduction=None):
+    red, rd, A, mp, keep = _red_args(reduction)
+    d = (rd if red else om.dims) - 6
+    res = np.zeros(sys_len(d), dtype=F)
+    pot = np.ascontiguousarray(pot, dtype=np.int32)
+    lib().orc_ne_self_intersection.restype = C.c_int
+    n = lib().orc_ne_self_intersection(f(c32(sites)), len(sites), om.ref, f(c32(T_fm)), f(c32(T_mf)), i(pot), red, rd, A, mp, f(res))
+    return res, n
+
+
+def ne_intersection(sites, T_ds, T_sd, src, T_fm_s, T_mf_s, dst, T_fm_d, T_mf_d, reduction=None):
+    red, rd, A, mp, keep = _red_args(reduction)
+    d = rd if red else src.dims
+    res = np.zeros(sys_len(d), dtype=F)
+    lib().orc_ne_intersection.restype = C.c_int
+    n = lib().orc_ne_intersection(f(c32(sites)), len(sites), f(c32(T_ds)), f(c32(T_sd)), src.ref, f(c32(T_fm_s)), f(c32(T_mf_s)),
+                                  dst.ref, f(c32(T_fm_d)), f(c32(T_mf_d)), red, rd, A, mp, f(res))
+    return res, n
+
+
+def count_self_intersections(sites, om, T_fm, T_mf, pot):
+    pot = np.ascontiguousarray(pot, dtype=np.int32)
+    return lib().orc_count_self_intersections(f(c32(sites)), len(sites), om.ref, f(c32(T_fm)), f(c32(T_mf)), i(pot))
+
+
+def count_intersections(sites, T_ds, src, T_mf_s, dst, T_fm_d):
+    return lib().orc_count_intersections(f(c32(sites)), len(sites), f(c32(T_ds)), src.ref, f(c32(T_mf_s)), dst.ref, f(c32(T_fm_d)))
