@@ -30,6 +30,15 @@ class ModelDesc(C.Structure):
     ]
 
 
+class OptOptions(C.Structure):
+    """dartk_opt_options (include/dartk.h); orc_opt_options has the same layout."""
+    _fields_ = [("numIterations", C.c_int32), ("distThreshold", C.c_float), ("normThreshold", C.c_float),
+                ("planeOffset", C.c_float), ("planeNormal", C.c_float * 3), ("regularization", C.c_float),
+                ("regularizationScaled", C.c_float), ("lambdaObsToMod", C.c_float), ("lambdaModToObs", C.c_float),
+                ("lambdaIntersection", C.c_float), ("huberDelta", C.c_float), ("focalLength", C.c_float),
+                ("predWidth", C.c_int32), ("predHeight", C.c_int32), ("predFl", C.c_float * 2)]
+
+
 def fptr(a):
     return a.ctypes.data_as(c_float_p)
 
@@ -121,6 +130,10 @@ def lib():
         "dartk_ne_intersection_parammap": [vp, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, vp, vp, vp, vp, vp],
         "dartk_count_self_intersections": [vp, C.c_int, vp, vp, c_int_p, vp],
         "dartk_count_intersections": [vp, C.c_int, c_float_p, vp, vp, c_int_p, vp],
+        "dartk_depth_to_vertices": [vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp],
+        "dartk_vertices_to_normals": [vp, vp, C.c_int, C.c_int, vp],
+        "dartk_prediction_to_depth": [vp, vp, C.c_int, C.c_int, vp],
+        "dartk_optimize_pose": [vp, vp, vp, C.c_int, C.c_int, C.POINTER(OptOptions), vp, C.c_int, vp, vp, vp, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)

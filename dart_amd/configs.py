@@ -1,0 +1,84 @@
+"""The synthetic workloads of BASELINE.json `configs`: every input is generated from seed 0xDA27.
+
+C1  rigid sphere r = 0.10 m at 0.6 m, one 80^3 SDF, 640x480 depth by SDF ray-cast.
+C2  Allegro hand (kinematics from models/allegro/allegro.xml; declared primitive proxies for the missing meshes),
+    640x480 depth of the TRUE pose, estimate starts 1.5 cm / 4 deg / 0.15 rad per joint away, prediction 320x240,
+    64^3 observation SDF, lambda_obsToMod = lambda_modToObs = 1.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import se3
+from .model import load_asset, sphere_model
+from .optimizer import OptimizationOptions
+
+F = np.float32
+SEED = 0xDA27
+FOCAL = 537.0     # optimization.h:43
+
+
+@dataclass
+class TrackingScene:
+    name: str
+    host_model: object
+    obs_layout: tuple
+    width: int
+    height: int
+    fl: tuple
+    pp: tuple
+    true_T_mc: np.ndarray
+    true_joints: np.ndarray
+    init_T_mc: np.ndarray
+    init_joints: np.ndarray
+    opts: OptimizationOptions
+    pred_width: int
+    pred_height: int
+
+
+def _perturb(T_mc, joints, limits, rng, trans, rot_deg, joint_delta):
+    d = rng.normal(size=3)
+    d = d / np.linalg.norm(d) * trans
+    a = rng.normal(size=3)
+    a = a / np.linalg.norm(a) * np.deg2rad(rot_deg)
+    T = se3.mul(se3.exp(np.concatenate([d, a]).astype(F)), T_mc)
+    j = joints + rng.choice([-1.0, 1.0], size=len(joints)) * joint_delta if len(joints) else joints
+    if len(joints):
+        j = np.clip(j, limits[:, 0], limits[:, 1])
+    return T, np.asarray(j, dtype=F)
+
+
+def config1(width=640, height=480):
+    rng = np.random.default_rng(SEED)
+    m = sphere_model(0.1).voxelize2(0.005, 0.10)
+    T_cm = se3.translation(0, 0, 0.6)
+    T_mc = se3.invert(T_cm)
+    init_T, init_j = _perturb(T_mc, np.zeros(0, dtype=F), None, rng, 0.02, 5.0, 0.0)
+    opts = OptimizationOptions(numIterations=5)
+    opts.distThreshold = [0.03]
+    s = width / 640.0
+    return TrackingScene("C1-sphere", m, m.obs_sdf_layout(), width, height, (FOCAL * s, FOCAL * s), (width / 2, height / 2),
+                         T_mc, np.zeros(0, dtype=F), init_T, init_j, opts, width // 2, height // 2)
+
+
+def _articulated(name, asset, width, height, z, rng, trans=0.015, rot=4.0, jd=0.15, pose_frac=(0.25, 0.6)):
+    m = load_asset(asset).voxelize(0.005, 0.10)
+    lim = np.asarray(m.joint_limits, dtype=np.float64).reshape(-1, 2)
+    joints = (lim[:, 0] + (lim[:, 1] - lim[:, 0]) * rng.uniform(pose_frac[0], pose_frac[1], len(lim))).astype(F)
+    # palm facing the camera, wrist down: rotate the model frame so that the fingers (model +z for allegro) point up (-y)
+    T_cm = se3.mul(se3.translation(0.0, 0.03, z), se3.exp(np.array([0, 0, 0, 1.2, 0.2, -0.1], dtype=F)))
+    T_mc = se3.invert(T_cm)
+    init_T, init_j = _perturb(T_mc, joints.astype(np.float64), lim, rng, trans, rot, jd)
+    opts = OptimizationOptions(numIterations=5)
+    s = width / 640.0
+    return TrackingScene(name, m, m.obs_sdf_layout(), width, height, (FOCAL * s, FOCAL * s), (width / 2, height / 2),
+                         T_mc, joints, init_T, init_j, opts, width // 2, height // 2)
+
+
+def config2(width=640, height=480):
+    return _articulated("C2-allegro", "allegro", width, height, 0.45, np.random.default_rng(SEED))
+
+
+def config2_left_hand(width=640, height=480):
+    """The asset-faithful articulated model (primitives straight from models/leftHand/leftHand.xml)."""
+    return _articulated("C2-leftHand", "left_hand", width, height, 0.45, np.random.default_rng(SEED + 1))

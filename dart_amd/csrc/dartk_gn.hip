@@ -1,0 +1,377 @@
+// dartk_gn.hip -- device-resident Gauss-Newton loops: the host side of Optimizer::optimizePose
+// (optimizer.cpp:423-522) with no host round trip inside an iteration. Per iteration the reference does: host
+// FK + 2 blocking uploads, a blocking count download, a memset + kernel + blocking system download per term,
+// Eigen assembly/solve on the host. Here an iteration is four launches on one stream
+//     ray-cast prediction | fused association + obs->mod normal equations | mod->obs normal equations
+//     | reduce + assemble + LDL^T solve + pose update + forward kinematics
+// and the pose never leaves HBM.
+#include "dartk_internal.h"
+#include "dartk_reduce.h"
+#include "dartk_kernels.h"
+#include "dartk_fk.h"
+
+namespace dartk {
+
+static constexpr int GN_MAX_BLOCKS = 256;     // one partial system per CU at most: the solve kernel sums them
+
+// -----------------------------------------------------------------------------------------------------
+// Fused association + obs->mod normal equations (obsToMod.cu:12-114 + :246-337). The reference materialises a
+// DataAssociatedPoint list between two kernels and reads the count back to the host; here the associated pixel
+// goes straight into an LDS row (the SDF gradient computed for the normal test is reused for the Jacobian) and
+// only the per-workgroup partial system and a count leave the CU.
+// -----------------------------------------------------------------------------------------------------
+template <int PPT>
+__global__ void __launch_bounds__(NE_BLOCK)
+fused_obs2mod_kernel(const float4 *__restrict__ vert, const float4 *__restrict__ norm, int nPix, ModelView m,
+                     float distThr, float normThr, float planeOffset, float pnx, float pny, float pnz, float huberDelta,
+                     float *__restrict__ slabs, int *__restrict__ count) {
+    extern __shared__ float lds[];
+    const int d = 6 + m.nJoints;
+    const int ld = row_len(d, false);
+    float *sT_fm = lds;
+    float *sT_mf = sT_fm + 12 * m.nFrames;
+    float *rows = sT_mf + 12 * m.nFrames;
+    int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ld);
+    stage_model(m, sT_fm, sT_mf, nullptr);
+    float T_mc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T_mc[i] = m.T_mc[i];
+
+    PairAcc<NE_BLOCK, PPT> acc;
+    acc.init(d, false);
+    int myCount = 0;
+    const int nTiles = (nPix + NE_BLOCK - 1) / NE_BLOCK;
+    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        const int index = tile * NE_BLOCK + threadIdx.x;
+        bool active = false;
+        AssocResult r;
+        f3 gf; gf.x = gf.y = gf.z = 0.f;
+        int frame = 0;
+        if (index < nPix) {
+            const float4 xc = vert[index];
+            if (xc.w > 0) {
+                r = associate_point(m, xc, distThr, planeOffset, pnx, pny, pnz);
+                if (r.grid >= 0) {
+                    frame = m.sdfFrame[r.grid];
+                    const SdfDev &s = m.sdfs[r.grid];
+                    const f3 xf = se3_apply_w(sT_fm + 12 * frame, r.xm.x, r.xm.y, r.xm.z, r.w);
+                    const f3 xg = grid_coords(s, xf);
+                    gf = grid_gradient(m.grids + s.dataOff, s.dimx, s.dimy, xg);
+                    // normal test (obsToMod.cu:83-96), same arithmetic as normal_test()
+                    active = true;
+                    const float4 nObs = norm[index];
+                    if (nObs.w > 0.0f) {
+                        float T_fc[12], T_cf[12], T_f[12];
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) T_f[i] = sT_fm[12 * frame + i];
+                        se3_mul(T_f, T_mc, T_fc);
+                        se3_invert(T_fc, T_cf);
+                        const float invLen = 1.0f / sqrtf(gf.x * gf.x + gf.y * gf.y + gf.z * gf.z + 0.0f * 0.0f);
+                        const float gw = 0.0f * invLen;
+                        const f3 n = se3_apply_w(T_cf, gf.x * invLen, gf.y * invLen, gf.z * invLen, gw);
+                        const float dp = (-1 * n.x) * nObs.x + (-1 * n.y) * nObs.y + (-1 * n.z) * nObs.z + (-1 * gw) * 0.0f;
+                        if (dp < normThr) active = false;
+                    }
+                }
+            }
+        }
+        int nActive;
+        const int slot = compact_slot<NE_BLOCK>(active, waveCnt, nActive);
+        if (active) {
+            float *row = rows + slot * ld;
+            const f3 gm = se3_rotate(sT_mf + 12 * frame, gf);
+            error_jacobian<false>(row, r.xm, r.w, m.depMask[frame], gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
+            const float err = r.err;
+            float rr, E;
+            if (fabsf(err) < huberDelta) { rr = -err; E = (float)(0.5 * (double)rr * (double)rr); }
+            else {
+                rr = (err < 0) ? huberDelta : -huberDelta;
+                E = (float)((double)huberDelta * ((double)fabsf(err) - 0.5 * (double)huberDelta));
+            }
+            row[d] = rr; row[d + 1] = E; row[d + 2] = 1.0f;
+        }
+        __syncthreads();
+        if (nActive) acc.accumulate(rows, ld, nActive);
+        myCount += nActive;
+        __syncthreads();
+    }
+    acc.store(slabs + (size_t)blockIdx.x * sys_size(d), sys_size(d));
+    if (threadIdx.x == 0 && myCount) atomicAdd(count, myCount);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// reduce + assemble + solve + update (optimizer.cpp:462-518), one workgroup.
+// -----------------------------------------------------------------------------------------------------
+struct SolveArgs {
+    const float *slabsA; int nBlocksA; const int *countA;     // obs->mod
+    const float *slabsB; int nBlocksB; const int *countB;     // mod->obs
+    const float *slabsC; int nBlocksC;                        // self-intersection (articulation-only system)
+    float lambdaA, lambdaB, lambdaC;
+    float regularization, lmLambda;
+    float *iterInfo;        // 8 floats or null
+    float *firstSystem;     // 3 packed systems or null
+};
+
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Pivoted LDL^T + solve by ONE wave on an LDS matrix (row stride ld). Same operation order as the oracle's
+// restatement of Eigen's ldlt().solve (oracle/dart_oracle.c orc_solve_ldlt). x may alias b.
+__device__ void ldlt_solve_wave(float *A, int ld, int n, const float *b, float *x, int *perm, float *y) {
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < n; i += 64) perm[i] = i;
+    wave_sync();
+    for (int k = 0; k < n; ++k) {
+        // pivot = first index of the largest |diagonal| in [k, n)
+        float best = -1.0f; int piv = n;
+        for (int i = k + lane; i < n; i += 64) {
+            const float v = fabsf(A[i * ld + i]);
+            if (v > best) { best = v; piv = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int op = __shfl_xor(piv, o);
+            if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
+        }
+        if (piv != k) {
+            for (int j = lane; j < n; j += 64) { const float t = A[k * ld + j]; A[k * ld + j] = A[piv * ld + j]; A[piv * ld + j] = t; }
+            wave_sync();
+            for (int i = lane; i < n; i += 64) { const float t = A[i * ld + k]; A[i * ld + k] = A[i * ld + piv]; A[i * ld + piv] = t; }
+            if (lane == 0) { const int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t; }
+            wave_sync();
+        }
+        const float dk = A[k * ld + k];
+        if (dk == 0.0f) continue;          // wave-uniform
+        for (int i = k + 1 + lane; i < n; i += 64) A[i * ld + k] /= dk;
+        wave_sync();
+        // trailing update on the lower triangle, mirrored (8x8 lane tile over (i,j))
+        const int m = n - k - 1;
+        const int li = lane >> 3, lj = lane & 7;
+        for (int bi = 0; bi < m; bi += 8) {
+            for (int bj = 0; bj <= bi; bj += 8) {
+                const int i = k + 1 + bi + li, j = k + 1 + bj + lj;
+                if (i < n && j <= i) {
+                    const float v = A[i * ld + j] - A[i * ld + k] * dk * A[j * ld + k];
+                    A[i * ld + j] = v;
+                    A[j * ld + i] = v;
+                }
+            }
+        }
+        wave_sync();
+    }
+    for (int i = lane; i < n; i += 64) y[i] = b[perm[i]];
+    wave_sync();
+    for (int j = 0; j < n; ++j) {          // forward substitution, column oriented (same op order as row oriented)
+        const float yj = y[j];
+        for (int i = j + 1 + lane; i < n; i += 64) y[i] -= A[i * ld + j] * yj;
+        wave_sync();
+    }
+    for (int i = lane; i < n; i += 64) {
+        const float dd = A[i * ld + i];
+        y[i] = (fabsf(dd) > 1.17549435e-38f) ? y[i] / dd : 0.0f;
+    }
+    wave_sync();
+    for (int j = n - 1; j >= 0; --j) {     // backward substitution with L^T, column oriented
+        const float yj = y[j];
+        for (int i = lane; i < j; i += 64) y[i] -= A[j * ld + i] * yj;
+        wave_sync();
+    }
+    for (int i = lane; i < n; i += 64) x[perm[i]] = y[i];
+    wave_sync();
+}
+
+__global__ void __launch_bounds__(256)
+gn_solve_single_kernel(ModelView m, SolveArgs a) {
+    extern __shared__ float lds[];
+    const int d = 6 + m.nJoints;
+    const int ad = d - 6;
+    const int S = sys_size(d), Sa = sys_size(ad);
+    const int ld = d + 1;
+    float *sysA = lds;
+    float *sysB = sysA + S;
+    float *sysC = sysB + S;
+    float *JTJ = sysC + S;                  // [d][ld]
+    float *eJ = JTJ + d * ld;
+    float *x = eJ + d;
+    float *y = x + d;
+    int *perm = reinterpret_cast<int *>(y + d);
+    const int tid = threadIdx.x;
+
+    // 1. fixed-order fp64 reduction of the per-workgroup partial systems
+    const bool keepA = a.slabsA && (*a.countA > 10);      // obsToMod.cu:646
+    for (int o = tid; o < S; o += blockDim.x) {
+        double s = 0.0;
+        if (keepA) for (int b = 0; b < a.nBlocksA; ++b) s += (double)a.slabsA[(size_t)b * S + o];
+        sysA[o] = (float)s;
+        s = 0.0;
+        if (a.slabsB) for (int b = 0; b < a.nBlocksB; ++b) s += (double)a.slabsB[(size_t)b * S + o];
+        sysB[o] = (float)s;
+    }
+    for (int o = tid; o < Sa; o += blockDim.x) {
+        double s = 0.0;
+        if (a.slabsC) for (int b = 0; b < a.nBlocksC; ++b) s += (double)a.slabsC[(size_t)b * Sa + o];
+        sysC[o] = (float)s;
+    }
+    __syncthreads();
+    if (a.firstSystem) {
+        for (int o = tid; o < S; o += blockDim.x) { a.firstSystem[o] = sysA[o]; a.firstSystem[S + o] = sysB[o]; }
+        for (int o = tid; o < Sa; o += blockDim.x) a.firstSystem[2 * S + o] = sysC[o];
+    }
+    // 2. unpack (optimizer.cpp:50-70) in the reference's term order, symmetrise, regularise, LM-scale
+    for (int idx = tid; idx < d * d; idx += blockDim.x) {
+        const int i = idx / d, j = idx % d;
+        const int lo = i < j ? i : j, hi = i < j ? j : i;          // upper (lo,hi) <- packed[hi(hi+1)/2 + lo]
+        float v = 0.0f;
+        if (a.slabsA) v += a.lambdaA * sysA[d + ((hi * (hi + 1)) >> 1) + lo];
+        if (a.slabsB) v += a.lambdaB * sysB[d + ((hi * (hi + 1)) >> 1) + lo];
+        if (a.slabsC && lo >= 6) {
+            const int p = lo - 6, q = hi - 6;
+            float t = 0.0f;
+            t += a.lambdaC * sysC[ad + ((q * (q + 1)) >> 1) + p];
+            v += t;
+        }
+        if (i == j) { v += a.regularization * 1.0f; v += a.lmLambda * v; }
+        JTJ[i * ld + j] = v;
+    }
+    for (int j = tid; j < d; j += blockDim.x) {
+        float v = 0.0f;
+        if (a.slabsA) v += a.lambdaA * sysA[j];
+        if (a.slabsB) v += a.lambdaB * sysB[j];
+        if (a.slabsC && j >= 6) { float t = 0.0f; t += a.lambdaC * sysC[j - 6]; v += t; }
+        eJ[j] = v;
+    }
+    if (tid == 0 && a.iterInfo) {
+        a.iterInfo[0] = a.slabsA ? a.lambdaA * sysA[S - 1] : 0.0f;
+        a.iterInfo[1] = a.slabsB ? a.lambdaB * sysB[S - 1] : 0.0f;
+        a.iterInfo[2] = a.slabsC ? a.lambdaC * sysC[Sa - 1] : 0.0f;
+        a.iterInfo[3] = a.slabsA ? (float)*a.countA : 0.0f;
+        a.iterInfo[4] = a.slabsB ? (float)*a.countB : 0.0f;
+        a.iterInfo[5] = a.iterInfo[6] = a.iterInfo[7] = 0.0f;
+    }
+    __syncthreads();
+    // 3. solve + update by wave 0
+    if (tid < 64) {
+        ldlt_solve_wave(JTJ, ld, d, eJ, x, perm, y);
+        if (tid == 0) {
+            float t6[6], dT[12], T[12], Tn[12], Tinv[12];
+            for (int i = 0; i < 6; ++i) t6[i] = -x[i];
+            se3_exp(t6, dT);
+            for (int i = 0; i < 12; ++i) T[i] = m.T_mc[i];
+            se3_mul(dT, T, Tn);
+            se3_invert(Tn, Tinv);
+            for (int i = 0; i < 12; ++i) { m.T_mc[i] = Tn[i]; m.T_cm[i] = Tinv[i]; }
+        }
+        for (int i = tid; i < m.nJoints; i += 64) {
+            const float v = m.joints[i] + (-x[6 + i]);
+            m.joints[i] = fminf(fmaxf(m.limits[2 * i], v), m.limits[2 * i + 1]);
+        }
+    }
+    __syncthreads();
+    // 4. forward kinematics for the next iteration (MirroredModel::setPose)
+    if (tid == 0) fk_device(m, 0);
+}
+
+static size_t solve_lds_bytes(int d) {
+    const int S = sys_size(d);
+    return sizeof(float) * (size_t)(3 * S + d * (d + 1) + 4 * d + 8);
+}
+
+}  // namespace dartk
+
+using namespace dartk;
+
+extern "C" {
+
+int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_norm, int width, int height,
+                        const dartk_opt_options *o, const float *d_cloud, int nCloud, const int32_t *d_potential,
+                        float *d_prediction, float *d_iterInfo, float *d_firstSystem, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_vert && d_norm && o, "dartk_optimize_pose: null argument");
+    DARTK_REQUIRE(width > 0 && height > 0 && (long long)width * height < (1ll << 31), "bad map size %dx%d", width, height);
+    DARTK_REQUIRE(o->numIterations >= 0, "negative iteration count");
+    const bool useA = o->lambdaObsToMod > 0, useB = o->lambdaModToObs > 0;
+    const bool useC = o->lambdaIntersection > 0 && nCloud > 0;
+    if (useB) {
+        DARTK_REQUIRE(d_prediction && o->predWidth > 0 && o->predHeight > 0, "mod->obs term needs a prediction buffer");
+        DARTK_REQUIRE(mod->obsVoxels > 0, "mod->obs term needs a model with an observation SDF");
+    }
+    if (useC) DARTK_REQUIRE(d_cloud && d_potential, "intersection term needs a collision cloud and potential matrix");
+    hipStream_t st = as_stream(stream);
+    ModelView &m = mod->v;
+    const int d = 6 + m.nJoints;
+    const int S = sys_size(d);
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    rc = ensure_partials(ws, (size_t)3 * GN_MAX_BLOCKS * S);
+    if (rc) return rc;
+    float *slabsA = ws->partials, *slabsB = slabsA + (size_t)GN_MAX_BLOCKS * S, *slabsC = slabsB + (size_t)GN_MAX_BLOCKS * S;
+    int *cntA = ws->counters, *cntB = ws->counters + 1;
+    float *d_T_gc = ws->sysScratch + 128;      // camera -> obs-SDF frame, frozen at the start (optimizer.cpp:446-448)
+
+    const int nPix = width * height;
+    const int tilesA = (nPix + NE_BLOCK - 1) / NE_BLOCK;
+    const int nBlocksA = tilesA < GN_MAX_BLOCKS ? tilesA : GN_MAX_BLOCKS;
+    const int nPred = o->predWidth * o->predHeight;
+    const int tilesB = (nPred + NE_BLOCK - 1) / NE_BLOCK;
+    const int nBlocksB = tilesB < GN_MAX_BLOCKS ? tilesB : GN_MAX_BLOCKS;
+    const int tilesC = (nCloud + NE_BLOCK - 1) / NE_BLOCK;
+    const int nBlocksC = tilesC < GN_MAX_BLOCKS ? tilesC : GN_MAX_BLOCKS;
+
+    if (useB) {
+        rc = gn_obs_sdf_build(d_vert, width, height, mod, o->focalLength, st);
+        if (rc) return rc;
+        DARTK_HIP(hipMemcpyAsync(d_T_gc, m.T_mc, 12 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    const size_t ldsA = sizeof(float) * (24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8);
+    const size_t ldsS = solve_lds_bytes(d);
+    DARTK_REQUIRE(ldsA <= 160 * 1024 && ldsS <= 160 * 1024, "LDS requirement exceeds 160 KiB");
+    if (ldsS > 64 * 1024)
+        DARTK_HIP(hipFuncSetAttribute((const void *)gn_solve_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS));
+
+    for (int it = 0; it < o->numIterations; ++it) {
+        if (useB) {
+            rc = gn_launch_raycast(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2),
+                                   o->predWidth, o->predHeight, 0, m, d_prediction, st);
+            if (rc) return rc;
+        }
+        DARTK_HIP(hipMemsetAsync(ws->counters, 0, 2 * sizeof(int), st));
+        if (useA) {
+#define DARTK_LAUNCH_FUSED(PPT_)                                                                                \
+    do {                                                                                                        \
+        auto kfn = fused_obs2mod_kernel<PPT_>;                                                                  \
+        if (ldsA > 64 * 1024)                                                                                   \
+            DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA)); \
+        hipLaunchKernelGGL(kfn, dim3(nBlocksA), dim3(NE_BLOCK), ldsA, st, (const float4 *)d_vert, (const float4 *)d_norm, \
+                           nPix, m, o->distThreshold, o->normThreshold, o->planeOffset, o->planeNormal[0],      \
+                           o->planeNormal[1], o->planeNormal[2], o->huberDelta, slabsA, cntA);                  \
+    } while (0)
+            if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_FUSED(3);
+            else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_FUSED(6);
+            else DARTK_LAUNCH_FUSED(20);
+#undef DARTK_LAUNCH_FUSED
+            DARTK_HIP(hipGetLastError());
+        }
+        if (useB) {
+            rc = gn_launch_ne_mod2obs(d_prediction, o->predWidth, o->predHeight, m, d_T_gc, slabsB, nBlocksB, cntB, st);
+            if (rc) return rc;
+        }
+        if (useC) {
+            rc = gn_launch_ne_self(d_cloud, nCloud, m, d_potential, slabsC, nBlocksC, st);
+            if (rc) return rc;
+        }
+        SolveArgs a;
+        a.slabsA = useA ? slabsA : nullptr; a.nBlocksA = nBlocksA; a.countA = cntA;
+        a.slabsB = useB ? slabsB : nullptr; a.nBlocksB = nBlocksB; a.countB = cntB;
+        a.slabsC = useC ? slabsC : nullptr; a.nBlocksC = nBlocksC;
+        a.lambdaA = o->lambdaObsToMod; a.lambdaB = o->lambdaModToObs; a.lambdaC = o->lambdaIntersection;
+        a.regularization = o->regularization; a.lmLambda = o->regularizationScaled;
+        a.iterInfo = d_iterInfo ? d_iterInfo + 8 * it : nullptr;
+        a.firstSystem = (it == 0) ? d_firstSystem : nullptr;
+        hipLaunchKernelGGL(gn_solve_single_kernel, dim3(1), dim3(256), ldsS, st, m, a);
+        DARTK_HIP(hipGetLastError());
+    }
+    return DARTK_OK;
+}
+
+}  // extern "C"

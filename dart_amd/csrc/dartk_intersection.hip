@@ -263,6 +263,31 @@ static int launch_inter(const float *d_sites, int nSites, int fullDims, int redD
     return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
 }
 
+// entry point for the device-resident Gauss-Newton loops: kernel only, slabs chosen by the caller
+int gn_launch_ne_self(const float *d_sites, int nSites, const ModelView &m, const int *d_pot, float *slabs, int nBlocks,
+                      hipStream_t st) {
+    const int fullDims = 6 + m.nJoints;
+    const int d = fullDims - 6;
+    const int S = sys_size(d);
+    size_t words = 24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8;
+    const size_t ldsBytes = words * sizeof(float);
+    DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
+#define DARTK_LAUNCH_SELF(PPT_)                                                                                 \
+    do {                                                                                                        \
+        auto kfn = ne_self_intersection_kernel<PPT_, 0>;                                                        \
+        if (ldsBytes > 64 * 1024)                                                                               \
+            DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, m, d_pot, \
+                           fullDims, nullptr, nullptr, slabs);                                                  \
+    } while (0)
+    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_SELF(3);
+    else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_SELF(6);
+    else DARTK_LAUNCH_SELF(20);
+#undef DARTK_LAUNCH_SELF
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
 }  // namespace dartk
 
 using namespace dartk;
@@ -272,7 +297,7 @@ extern "C" {
 int dartk_ne_self_intersection(const float *d_sites, int nSites, int dims, dartk_model_t h, const int32_t *d_pot,
                                float *d_result, void *stream) {
     Model *mod = reinterpret_cast<Model *>(h);
-    DARTK_REQUIRE(d_sites && d_pot && d_result, "dartk_ne_self_intersection: null argument");
+    DARTK_REQUIRE((d_sites || nSites == 0) && d_pot && d_result, "dartk_ne_self_intersection: null argument");
     int rc = check_sites(mod, nSites);
     if (rc) return rc;
     return launch_self<0>(d_sites, nSites, dims, dims, mod, nullptr, nullptr, d_pot, d_result, as_stream(stream));
@@ -280,7 +305,7 @@ int dartk_ne_self_intersection(const float *d_sites, int nSites, int dims, dartk
 int dartk_ne_self_intersection_reduced(const float *d_sites, int nSites, int fullDims, int redDims, dartk_model_t h,
                                        const float *d_A, const int32_t *d_pot, float *d_result, void *stream) {
     Model *mod = reinterpret_cast<Model *>(h);
-    DARTK_REQUIRE(d_sites && d_pot && d_result && d_A, "dartk_ne_self_intersection_reduced: null argument");
+    DARTK_REQUIRE((d_sites || nSites == 0) && d_pot && d_result && d_A, "dartk_ne_self_intersection_reduced: null argument");
     DARTK_REQUIRE(redDims > 6 && redDims <= fullDims, "redDims %d must be in (6,%d]", redDims, fullDims);
     int rc = check_sites(mod, nSites);
     if (rc) return rc;
@@ -289,7 +314,7 @@ int dartk_ne_self_intersection_reduced(const float *d_sites, int nSites, int ful
 int dartk_ne_self_intersection_parammap(const float *d_sites, int nSites, int fullDims, int redDims, dartk_model_t h,
                                         const int32_t *d_map, const int32_t *d_pot, float *d_result, void *stream) {
     Model *mod = reinterpret_cast<Model *>(h);
-    DARTK_REQUIRE(d_sites && d_pot && d_result && d_map, "dartk_ne_self_intersection_parammap: null argument");
+    DARTK_REQUIRE((d_sites || nSites == 0) && d_pot && d_result && d_map, "dartk_ne_self_intersection_parammap: null argument");
     DARTK_REQUIRE(redDims > 6 && redDims <= fullDims, "redDims %d must be in (6,%d]", redDims, fullDims);
     int rc = check_sites(mod, nSites);
     if (rc) return rc;
@@ -299,14 +324,14 @@ int dartk_ne_self_intersection_parammap(const float *d_sites, int nSites, int fu
 int dartk_ne_intersection(const float *d_sites, int nSites, int dims, const float *h_T_ds, const float *h_T_sd,
                           dartk_model_t hs, dartk_model_t hd, float *d_result, void *stream) {
     Model *src = reinterpret_cast<Model *>(hs), *dst = reinterpret_cast<Model *>(hd);
-    DARTK_REQUIRE(d_sites && h_T_ds && h_T_sd && src && dst && d_result, "dartk_ne_intersection: null argument");
+    DARTK_REQUIRE((d_sites || nSites == 0) && h_T_ds && h_T_sd && src && dst && d_result, "dartk_ne_intersection: null argument");
     return launch_inter<0>(d_sites, nSites, dims, dims, h_T_ds, h_T_sd, src, dst, nullptr, nullptr, d_result, as_stream(stream));
 }
 int dartk_ne_intersection_reduced(const float *d_sites, int nSites, int fullDims, int redDims, const float *h_T_ds,
                                   const float *h_T_sd, dartk_model_t hs, dartk_model_t hd, const float *d_A,
                                   float *d_result, void *stream) {
     Model *src = reinterpret_cast<Model *>(hs), *dst = reinterpret_cast<Model *>(hd);
-    DARTK_REQUIRE(d_sites && h_T_ds && h_T_sd && src && dst && d_result && d_A, "dartk_ne_intersection_reduced: null argument");
+    DARTK_REQUIRE((d_sites || nSites == 0) && h_T_ds && h_T_sd && src && dst && d_result && d_A, "dartk_ne_intersection_reduced: null argument");
     DARTK_REQUIRE(redDims >= 6 && redDims <= fullDims, "redDims %d must be in [6,%d]", redDims, fullDims);
     return launch_inter<1>(d_sites, nSites, fullDims, redDims, h_T_ds, h_T_sd, src, dst, d_A, nullptr, d_result, as_stream(stream));
 }
@@ -314,7 +339,7 @@ int dartk_ne_intersection_parammap(const float *d_sites, int nSites, int fullDim
                                    const float *h_T_sd, dartk_model_t hs, dartk_model_t hd, const int32_t *d_map,
                                    float *d_result, void *stream) {
     Model *src = reinterpret_cast<Model *>(hs), *dst = reinterpret_cast<Model *>(hd);
-    DARTK_REQUIRE(d_sites && h_T_ds && h_T_sd && src && dst && d_result && d_map, "dartk_ne_intersection_parammap: null argument");
+    DARTK_REQUIRE((d_sites || nSites == 0) && h_T_ds && h_T_sd && src && dst && d_result && d_map, "dartk_ne_intersection_parammap: null argument");
     DARTK_REQUIRE(redDims >= 6 && redDims <= fullDims, "redDims %d must be in [6,%d]", redDims, fullDims);
     return launch_inter<2>(d_sites, nSites, fullDims, redDims, h_T_ds, h_T_sd, src, dst, nullptr, d_map, d_result, as_stream(stream));
 }
@@ -322,7 +347,7 @@ int dartk_ne_intersection_parammap(const float *d_sites, int nSites, int fullDim
 int dartk_count_self_intersections(const float *d_sites, int nSites, dartk_model_t h, const int32_t *d_pot,
                                    int32_t *h_count, void *stream) {
     Model *mod = reinterpret_cast<Model *>(h);
-    DARTK_REQUIRE(d_sites && d_pot && h_count && mod, "dartk_count_self_intersections: null argument");
+    DARTK_REQUIRE((d_sites || nSites == 0) && d_pot && h_count && mod, "dartk_count_self_intersections: null argument");
     Workspace *ws;
     int rc = get_workspace(&ws);
     if (rc) return rc;
@@ -339,7 +364,7 @@ int dartk_count_self_intersections(const float *d_sites, int nSites, dartk_model
 int dartk_count_intersections(const float *d_sites, int nSites, const float *h_T_ds, dartk_model_t hs, dartk_model_t hd,
                               int32_t *h_count, void *stream) {
     Model *src = reinterpret_cast<Model *>(hs), *dst = reinterpret_cast<Model *>(hd);
-    DARTK_REQUIRE(d_sites && h_T_ds && h_count && src && dst, "dartk_count_intersections: null argument");
+    DARTK_REQUIRE((d_sites || nSites == 0) && h_T_ds && h_count && src && dst, "dartk_count_intersections: null argument");
     Workspace *ws;
     int rc = get_workspace(&ws);
     if (rc) return rc;

@@ -312,6 +312,33 @@ size_t ne_mod2obs_lds_bytes(const ModelView &m, int d, int red) {
     return words * sizeof(float);
 }
 
+// launches the kernel only: partial systems land in slabs[nBlocks][S] (nBlocks chosen by the caller)
+template <int RED, bool TRUNC>
+static int launch_ne_mod2obs_kernel(int fullDims, int redDims, const float *d_pred, int width, int height,
+                                    const ModelView &m, const float *d_T_gc, float trunc, const float *d_A,
+                                    const int *d_map, float *slabs, int nBlocks, int *d_num, hipStream_t st) {
+    const int d = RED ? redDims : fullDims;
+    const int S = sys_size(d);
+    const int nPix = width * height;
+    const size_t ldsBytes = ne_mod2obs_lds_bytes(m, d, RED);
+    DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
+    const float4 *pred = reinterpret_cast<const float4 *>(d_pred);
+#define DARTK_LAUNCH_M2O(PPT_)                                                                                  \
+    do {                                                                                                        \
+        auto kfn = ne_mod2obs_kernel<PPT_, RED, TRUNC>;                                                         \
+        if (ldsBytes > 64 * 1024)                                                                               \
+            DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, pred, nPix, m.modelId, m, d_T_gc, trunc,     \
+                           redDims, d_A, d_map, slabs, d_num);                                                  \
+    } while (0)
+    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_M2O(3);
+    else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_M2O(6);
+    else DARTK_LAUNCH_M2O(20);
+#undef DARTK_LAUNCH_M2O
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
 template <int RED, bool TRUNC>
 static int launch_ne_mod2obs(int fullDims, int redDims, const float *d_pred, int width, int height, Model *mod,
                              const float *d_T_gc, float trunc, const float *d_A, const int *d_map, float *d_result,
@@ -332,23 +359,41 @@ static int launch_ne_mod2obs(int fullDims, int redDims, const float *d_pred, int
     rc = ensure_partials(ws, (size_t)nBlocks * S);
     if (rc) return rc;
     if (zeroCounter) DARTK_HIP(hipMemsetAsync(d_num, 0, sizeof(int), st));
-    const size_t ldsBytes = ne_mod2obs_lds_bytes(m, d, RED);
-    DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
-    const float4 *pred = reinterpret_cast<const float4 *>(d_pred);
-#define DARTK_LAUNCH_M2O(PPT_)                                                                                  \
-    do {                                                                                                        \
-        auto kfn = ne_mod2obs_kernel<PPT_, RED, TRUNC>;                                                         \
-        if (ldsBytes > 64 * 1024)                                                                               \
-            DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
-        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, pred, nPix, m.modelId, m, d_T_gc, trunc,     \
-                           redDims, d_A, d_map, ws->partials, d_num);                                           \
-    } while (0)
-    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_M2O(3);
-    else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_M2O(6);
-    else DARTK_LAUNCH_M2O(20);
-#undef DARTK_LAUNCH_M2O
-    DARTK_HIP(hipGetLastError());
+    rc = launch_ne_mod2obs_kernel<RED, TRUNC>(fullDims, redDims, d_pred, width, height, m, d_T_gc, trunc, d_A, d_map,
+                                              ws->partials, nBlocks, d_num, st);
+    if (rc) return rc;
     return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
+}
+
+// entry points for the device-resident Gauss-Newton loop (dartk_gn.hip)
+int gn_launch_ne_mod2obs(const float *d_pred, int width, int height, const ModelView &m, const float *d_T_gc,
+                         float *slabs, int nBlocks, int *d_num, hipStream_t st) {
+    return launch_ne_mod2obs_kernel<0, false>(6 + m.nJoints, 6 + m.nJoints, d_pred, width, height, m, d_T_gc, 0.f, nullptr,
+                                              nullptr, slabs, nBlocks, d_num, st);
+}
+int gn_launch_raycast(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
+                      float *d_prediction, hipStream_t st) {
+    const int tiles = ((width + 7) / 8) * ((height + 7) / 8);
+    hipLaunchKernelGGL(raycast_prediction_kernel, dim3((tiles + 3) / 4), dim3(256), sizeof(float) * 24 * (size_t)m.nSdfs, st,
+                       flx, fly, ppx, ppy, width, height, modelNum, m, (float4 *)d_prediction, 0.0f);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+int gn_launch_cull(float *d_pred, int pw, int ph, const float *d_obs, int ow, int oh, hipStream_t st) {
+    hipLaunchKernelGGL(cull_unobservable_kernel, dim3((pw * ph + 255) / 256), dim3(256), 0, st, (float4 *)d_pred, pw, ph,
+                       (const float4 *)d_obs, ow, oh);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+int gn_obs_sdf_build(const float *d_vert, int width, int height, Model *mod, float focalLength, hipStream_t st) {
+    const ModelView &m = mod->v;
+    const int n = (int)mod->obsVoxels;
+    hipLaunchKernelGGL(splat_obs_sdf_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float4 *)d_vert, width, height, m, focalLength);
+    DARTK_HIP(hipGetLastError());
+    int rc = launch_distance_transform_3d(m.obsData, mod->dtTmp, m.obs.dimx, m.obs.dimy, m.obs.dimz, 1, st);
+    if (rc) return rc;
+    DARTK_HIP(hipMemcpyAsync(m.obsData, mod->dtTmp, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, st));  // optimizer.cpp:215
+    return DARTK_OK;
 }
 
 // gpu_errorModToObs, modToObs.cu:649-680 (prediction used in camera coordinates, as the reference does)
@@ -435,15 +480,7 @@ int dartk_obs_sdf_build(const float *d_vert, int width, int height, dartk_model_
     DARTK_REQUIRE(mod && d_vert, "dartk_obs_sdf_build: null argument");
     DARTK_REQUIRE(mod->obsVoxels > 0, "model has no observation SDF");
     DARTK_REQUIRE(width > 0 && height > 0, "bad map size");
-    hipStream_t st = as_stream(stream);
-    const ModelView &m = mod->v;
-    const int n = (int)mod->obsVoxels;
-    hipLaunchKernelGGL(splat_obs_sdf_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float4 *)d_vert, width, height, m, focalLength);
-    DARTK_HIP(hipGetLastError());
-    int rc = launch_distance_transform_3d(m.obsData, mod->dtTmp, m.obs.dimx, m.obs.dimy, m.obs.dimz, 1, st);
-    if (rc) return rc;
-    DARTK_HIP(hipMemcpyAsync(m.obsData, mod->dtTmp, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, st));  // optimizer.cpp:215
-    return DARTK_OK;
+    return gn_obs_sdf_build(d_vert, width, height, mod, focalLength, as_stream(stream));
 }
 
 static int upload_T(const float *h_T, float **d_T, hipStream_t st) {

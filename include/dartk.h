@@ -179,6 +179,44 @@ int dartk_count_self_intersections(const float *d_sites, int nSites, dartk_model
 int dartk_count_intersections(const float *d_sites, int nSites, const float *h_T_ds, dartk_model_t src,
                               dartk_model_t dst, int32_t *h_count, void *stream);
 
+/* ------------------------------------------------------------------ synthetic depth front end */
+/* depthToVertices<float> (img_proc/organized_point_cloud.h; .cu:11-40, :381-395): back-projection
+ * ((u-pp.x)*z/f.x, (v-pp.y)*z/f.y, z, 1) for range.x <= z <= range.y, else w = 0. */
+int dartk_depth_to_vertices(const float *d_depth, float *d_vert, int width, int height, float ppx, float ppy,
+                            float flx, float fly, float rangeMin, float rangeMax, void *stream);
+/* verticesToNormals (organized_point_cloud.cu:265-305, :437-449) */
+int dartk_vertices_to_normals(const float *d_vert, float *d_norm, int width, int height, void *stream);
+/* No counterpart in the reference (it reads sensors / renders with OpenGL): depth image = z channel of a
+ * ray-cast prediction map, the on-device synthetic depth source north_star asks for. */
+int dartk_prediction_to_depth(const float *d_pred, float *d_depth, int width, int height, void *stream);
+
+/* ------------------------------------------------------------------ device-resident Gauss-Newton loops */
+/* OptimizationOptions (optimization.h:9-72) for one model + the PredictionRenderer geometry the Optimizer
+ * constructor derives (optimizer.cpp:72-98: prediction size and focal length scaled by predWidth/depthWidth). */
+typedef struct {
+    int32_t numIterations;
+    float distThreshold, normThreshold, planeOffset;
+    float planeNormal[3];
+    float regularization, regularizationScaled;
+    float lambdaObsToMod, lambdaModToObs, lambdaIntersection;
+    float huberDelta, focalLength;
+    int32_t predWidth, predHeight;
+    float predFl[2];
+} dartk_opt_options;
+
+/* Optimizer::optimizePose (optimizer.h:25-35 / optimizer.cpp:423-522) for a NullReduction pose, entirely on the
+ * device: obs-SDF build (if lambdaModToObs>0), then numIterations x { ray-cast prediction, association + obs->mod
+ * normal equations, mod->obs normal equations, optional self-intersection, assemble (unpack, :50-70), A = JTJ +
+ * reg*I, A_ii += lm*A_ii, LDL^T solve, T_mc <- exp(d)*T_mc, joints clamped, forward kinematics }. The pose is the
+ * model's current pose (dartk_model_set_pose) and is updated in place; read it back with
+ * dartk_model_get_transforms. d_prediction: float4[predWidth*predHeight] scratch. Optional outputs:
+ * d_iterInfo[8*numIterations] = {errObsToMod, errModToObs, errIntersection, nAssociated, nPredicted,0,0,0} per
+ * iteration (Optimizer::_iterationSummaries); d_firstSystem = the first iteration's three packed systems. */
+int dartk_optimize_pose(dartk_model_t m, const float *d_vert, const float *d_norm, int width, int height,
+                        const dartk_opt_options *opts, const float *d_collisionCloud, int nCloud,
+                        const int32_t *d_potentialIntersection, float *d_prediction, float *d_iterInfo,
+                        float *d_firstSystem, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

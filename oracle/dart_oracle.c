@@ -916,7 +916,7 @@ void orc_solve_ldlt(const float *Ain, const float *b, int n, float *x) {
         /* Eigen's pseudo-inverse of D: tiny pivots give 0 (LDLT::_solve_impl tolerance = 1/max float) */
         y[i] = (fabsf(d) > FLT_MIN) ? y[i] / d : 0.0f;
     }
-    for (int i = n - 1; i >= 0; --i) { float s = y[i]; for (int j = i + 1; j < n; ++j) s -= A[j * n + i] * y[j]; y[i] = s; }
+    for (int i = n - 1; i >= 0; --i) { float s = y[i]; for (int j = n - 1; j > i; --j) s -= A[j * n + i] * y[j]; y[i] = s; }
     for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
     free(A); free(perm); free(y);
 }

@@ -269,3 +269,22 @@ def count_self_intersections(sites, om, T_fm, T_mf, pot):
 
 def count_intersections(sites, T_ds, src, T_mf_s, dst, T_fm_d):
     return lib().orc_count_intersections(f(c32(sites)), len(sites), f(c32(T_ds)), src.ref, f(c32(T_mf_s)), dst.ref, f(c32(T_fm_d)))
+
+
+# ---------------------------------------------------------------------------------------------- optimizer loops
+def optimize_pose(om, T_mc, joints, vert, norm, opts_struct, cloud=None, potential=None):
+    """orc_optimize_pose. opts_struct: dart_amd._abi.OptOptions (same layout as orc_opt_options).
+    Returns (T_mc, joints, iter_info [n,8], first_system)."""
+    T = c32(T_mc).copy()
+    j = c32(joints).copy() if om.n_joints else np.zeros(1, dtype=F)
+    n_obs = int(np.prod(om.desc.obs_sdf_dim[:])) if om.desc.obs_sdf_dim[0] else 1
+    obs = np.zeros(max(n_obs, 1), dtype=F)
+    info = np.zeros((max(opts_struct.numIterations, 1), 8), dtype=F)
+    first = np.zeros(3 * sys_len(om.dims), dtype=F)
+    n_cloud = 0 if cloud is None else len(cloud)
+    cl = c32(cloud) if n_cloud else np.zeros(4, dtype=F)
+    pot = np.ascontiguousarray(potential, dtype=np.int32) if potential is not None else np.zeros(1, dtype=np.int32)
+    h, w = vert.shape[:2]
+    lib().orc_optimize_pose(om.ref, f(T), f(j), f(c32(vert)), f(c32(norm)), w, h, C.byref(opts_struct), f(cl), n_cloud, i(pot),
+                            f(obs), f(info), f(first))
+    return T, j[:om.n_joints], info, first
