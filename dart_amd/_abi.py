@@ -133,6 +133,8 @@ def lib():
         "dartk_depth_to_vertices": [vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp],
         "dartk_vertices_to_normals": [vp, vp, C.c_int, C.c_int, vp],
         "dartk_prediction_to_depth": [vp, vp, C.c_int, C.c_int, vp],
+        "dartk_profile_begin": [],
+        "dartk_profile_end": [c_float_p, c_int_p],
         "dartk_optimize_pose": [vp, vp, vp, C.c_int, C.c_int, C.POINTER(OptOptions), vp, C.c_int, vp, vp, vp, vp, vp],
     }
     for name, args in sigs.items():

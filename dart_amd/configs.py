@@ -16,6 +16,12 @@ from .optimizer import OptimizationOptions
 F = np.float32
 SEED = 0xDA27
 FOCAL = 537.0     # optimization.h:43
+# The single-model association rejects a point when dot(-grad_c, n_obs) < normThreshold (obsToMod.cu:84-96): with the
+# reference's own normal maps (outward normals, organized_point_cloud.cu:286-299) and the default -0.1 that gate is
+# inverted and drops ~94 % of the well-aligned points. The workloads disable the gate
+# (threshold below -1) so that EVERY associated point enters the normal equations -- the heavier, conservative
+# choice for a benchmark; tests cover the default -0.1 as well.
+NORM_GATE_OFF = -2.0
 
 
 @dataclass
@@ -56,6 +62,7 @@ def config1(width=640, height=480):
     init_T, init_j = _perturb(T_mc, np.zeros(0, dtype=F), None, rng, 0.02, 5.0, 0.0)
     opts = OptimizationOptions(numIterations=5)
     opts.distThreshold = [0.03]
+    opts.normThreshold = NORM_GATE_OFF
     s = width / 640.0
     return TrackingScene("C1-sphere", m, m.obs_sdf_layout(), width, height, (FOCAL * s, FOCAL * s), (width / 2, height / 2),
                          T_mc, np.zeros(0, dtype=F), init_T, init_j, opts, width // 2, height // 2)
@@ -70,6 +77,7 @@ def _articulated(name, asset, width, height, z, rng, trans=0.015, rot=4.0, jd=0.
     T_mc = se3.invert(T_cm)
     init_T, init_j = _perturb(T_mc, joints.astype(np.float64), lim, rng, trans, rot, jd)
     opts = OptimizationOptions(numIterations=5)
+    opts.normThreshold = NORM_GATE_OFF
     s = width / 640.0
     return TrackingScene(name, m, m.obs_sdf_layout(), width, height, (FOCAL * s, FOCAL * s), (width / 2, height / 2),
                          T_mc, joints, init_T, init_j, opts, width // 2, height // 2)

@@ -10,9 +10,28 @@
 #include "dartk_kernels.h"
 #include "dartk_fk.h"
 
+#include <vector>
+
 namespace dartk {
 
 static constexpr int GN_MAX_BLOCKS = 256;     // one partial system per CU at most: the solve kernel sums them
+
+// ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg) -------
+struct ProfEvent { int cls; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfEvent> g_prof;
+struct ProfScope {
+    hipStream_t st; int idx;
+    ProfScope(int cls, hipStream_t s) : st(s), idx(-1) {
+        if (!g_prof_on) return;
+        ProfEvent e; e.cls = cls;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+        (void)hipEventRecord(e.a, st);
+        g_prof.push_back(e);
+        idx = (int)g_prof.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, st); }
+};
 
 // -----------------------------------------------------------------------------------------------------
 // Fused association + obs->mod normal equations (obsToMod.cu:12-114 + :246-337). The reference materialises a
@@ -282,6 +301,30 @@ using namespace dartk;
 
 extern "C" {
 
+int dartk_profile_begin(void) {
+    for (auto &e : g_prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    g_prof.clear();
+    g_prof_on = true;
+    return DARTK_OK;
+}
+
+int dartk_profile_end(float *h_ms_total, int32_t *h_launches) {
+    DARTK_REQUIRE(h_ms_total && h_launches, "dartk_profile_end: null argument");
+    g_prof_on = false;
+    for (int c = 0; c < DARTK_PROF_CLASSES; ++c) { h_ms_total[c] = 0.0f; h_launches[c] = 0; }
+    DARTK_HIP(hipDeviceSynchronize());
+    for (auto &e : g_prof) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess && e.cls >= 0 && e.cls < DARTK_PROF_CLASSES) {
+            h_ms_total[e.cls] += ms;
+            h_launches[e.cls] += 1;
+        }
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    g_prof.clear();
+    return DARTK_OK;
+}
+
 int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_norm, int width, int height,
                         const dartk_opt_options *o, const float *d_cloud, int nCloud, const int32_t *d_potential,
                         float *d_prediction, float *d_iterInfo, float *d_firstSystem, void *stream) {
@@ -319,7 +362,10 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     const int nBlocksC = tilesC < GN_MAX_BLOCKS ? tilesC : GN_MAX_BLOCKS;
 
     if (useB) {
-        rc = gn_obs_sdf_build(d_vert, width, height, mod, o->focalLength, st);
+        {
+            ProfScope ps(DARTK_PROF_OBS_SDF, st);
+            rc = gn_obs_sdf_build(d_vert, width, height, mod, o->focalLength, st);
+        }
         if (rc) return rc;
         DARTK_HIP(hipMemcpyAsync(d_T_gc, m.T_mc, 12 * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
@@ -331,12 +377,14 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
 
     for (int it = 0; it < o->numIterations; ++it) {
         if (useB) {
+            ProfScope ps(DARTK_PROF_RAYCAST, st);
             rc = gn_launch_raycast(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2),
                                    o->predWidth, o->predHeight, 0, m, d_prediction, st);
             if (rc) return rc;
         }
         DARTK_HIP(hipMemsetAsync(ws->counters, 0, 2 * sizeof(int), st));
         if (useA) {
+            ProfScope ps(DARTK_PROF_FUSED_OBS2MOD, st);
 #define DARTK_LAUNCH_FUSED(PPT_)                                                                                \
     do {                                                                                                        \
         auto kfn = fused_obs2mod_kernel<PPT_>;                                                                  \
@@ -353,10 +401,12 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
             DARTK_HIP(hipGetLastError());
         }
         if (useB) {
+            ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
             rc = gn_launch_ne_mod2obs(d_prediction, o->predWidth, o->predHeight, m, d_T_gc, slabsB, nBlocksB, cntB, st);
             if (rc) return rc;
         }
         if (useC) {
+            ProfScope ps(DARTK_PROF_NE_SELF, st);
             rc = gn_launch_ne_self(d_cloud, nCloud, m, d_potential, slabsC, nBlocksC, st);
             if (rc) return rc;
         }
@@ -368,7 +418,10 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         a.regularization = o->regularization; a.lmLambda = o->regularizationScaled;
         a.iterInfo = d_iterInfo ? d_iterInfo + 8 * it : nullptr;
         a.firstSystem = (it == 0) ? d_firstSystem : nullptr;
-        hipLaunchKernelGGL(gn_solve_single_kernel, dim3(1), dim3(256), ldsS, st, m, a);
+        {
+            ProfScope ps(DARTK_PROF_SOLVE, st);
+            hipLaunchKernelGGL(gn_solve_single_kernel, dim3(1), dim3(256), ldsS, st, m, a);
+        }
         DARTK_HIP(hipGetLastError());
     }
     return DARTK_OK;

@@ -217,6 +217,17 @@ int dartk_optimize_pose(dartk_model_t m, const float *d_vert, const float *d_nor
                         const int32_t *d_potentialIntersection, float *d_prediction, float *d_iterInfo,
                         float *d_firstSystem, void *stream);
 
+/* ------------------------------------------------------------------ measurement (no reference counterpart) */
+/* Per-kernel-class device time of the Gauss-Newton loops, measured with HIP events recorded on the launch stream
+ * around every launch between dartk_profile_begin() and dartk_profile_end(). Used by bench.py's roofline leg;
+ * adds two event records per launch, so throughput is timed with profiling off. */
+enum dartk_prof_class {
+    DARTK_PROF_OBS_SDF = 0, DARTK_PROF_RAYCAST = 1, DARTK_PROF_FUSED_OBS2MOD = 2, DARTK_PROF_NE_MOD2OBS = 3,
+    DARTK_PROF_NE_SELF = 4, DARTK_PROF_SOLVE = 5, DARTK_PROF_REFINE = 6, DARTK_PROF_OTHER = 7, DARTK_PROF_CLASSES = 8
+};
+int dartk_profile_begin(void);
+int dartk_profile_end(float *h_ms_total /*[DARTK_PROF_CLASSES]*/, int32_t *h_launches /*[DARTK_PROF_CLASSES]*/);
+
 #ifdef __cplusplus
 }
 #endif

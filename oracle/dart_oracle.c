@@ -151,7 +151,18 @@ static inline float grid_at(const orc_grid *g, int x, int y, int z) {
     return g->data[x + g->dim[0] * (y + g->dim[1] * z)];
 }
 
+/* trilinear-lookup counters by caller category: feed the algorithmic-bytes figures of bench.py */
+static long long g_lookups[ORC_STAT_CATEGORIES];
+static int g_cat = 0;
+static int g_stats_on = 0;
+#pragma omp threadprivate(g_cat)
+void orc_stats_reset(void) { for (int i = 0; i < ORC_STAT_CATEGORIES; ++i) g_lookups[i] = 0; }
+void orc_stats_enable(int on) { g_stats_on = on; }
+void orc_stats_get(long long *out) { for (int i = 0; i < ORC_STAT_CATEGORIES; ++i) out[i] = g_lookups[i]; }
+static inline int stat_enter(int cat) { int old = g_cat; g_cat = cat; return old; }
+
 float orc_grid_value_interp(const orc_grid *g, const float *p) {
+    if (g_stats_on) g_lookups[g_cat]++;   /* statistics runs are single-threaded */
     const int x0 = (int)(p[0] - 0.5); const float fx = (p[0] - 0.5) - x0;
     const int y0 = (int)(p[1] - 0.5); const float fy = (p[1] - 0.5) - y0;
     const int z0 = (int)(p[2] - 0.5); const float fz = (p[2] - 0.5) - z0;
@@ -294,6 +305,7 @@ int orc_assoc_single(const float *vert, const float *norm, int width, int height
                      float planeOffset, const float *planeNormal, orc_da_point *pts,
                      int32_t *dbgDA, float *dbgErr, float *dbgNorm) {
     int count = 0;
+    const int oldcat = stat_enter(ORC_STAT_ASSOC);
     for (int index = 0; index < width * height; ++index) {
         if (dbgDA) dbgDA[index] = -1;
         if (dbgErr) dbgErr[index] = NAN;
@@ -324,7 +336,9 @@ int orc_assoc_single(const float *vert, const float *norm, int width, int height
             se3_apply4(T_fm + 12 * f, xm, xf);
             const orc_grid sdf = model_sdf(m, grid);
             orc_grid_coords(&sdf, xf, xg);
+            stat_enter(ORC_STAT_ASSOC_GRAD);
             orc_grid_gradient_interp(&sdf, xg, gr);
+            stat_enter(ORC_STAT_ASSOC);
             /* nPred = -1 * (SE3Invert(T_fm[f]*T_mc) * normalize(float4(grad,0))), obsToMod.cu:84 */
             float T_fc[12], T_cf[12];
             orc_se3_mul(T_fm + 12 * f, T_mc, T_fc);
@@ -349,6 +363,7 @@ int orc_assoc_single(const float *vert, const float *norm, int width, int height
         pts[count].error = sdfError;
         ++count;
     }
+    stat_enter(oldcat);
     return count;
 }
 
@@ -455,6 +470,7 @@ void orc_ne_obs2mod(const float *vert, const orc_model *m, const float *T_mc, co
     const int fullDims = 6 + m->n_joints;
     const int dims = reduction ? redDims : fullDims;
     sys_acc s = sys_new(dims);
+    const int oldcat = stat_enter(ORC_STAT_NE_OBS2MOD);
     if (nPoints > 10) { /* obsToMod.cu:646,723,783 */
         float *de = (float *)malloc(sizeof(float) * (size_t)(fullDims + dims));
         float *Jr = de + fullDims;
@@ -490,6 +506,7 @@ void orc_ne_obs2mod(const float *vert, const orc_model *m, const float *T_mc, co
         }
         free(de);
     }
+    stat_enter(oldcat);
     sys_emit(&s, result);
 }
 
@@ -516,6 +533,7 @@ void orc_raycast_prediction(float flx, float fly, float ppx, float ppy, int widt
                             float levelSet, float *prediction) {
     float T_cm[12];
     orc_se3_invert(T_mc, T_cm);
+    const int oldcat = stat_enter(ORC_STAT_RAYCAST);
     for (int y = 0; y < height; ++y) for (int x = 0; x < width; ++x) {
         const int index = x + y * width;
         float *pr = prediction + 4 * index;
@@ -582,6 +600,7 @@ void orc_raycast_prediction(float flx, float fly, float ppx, float ppy, int widt
 #undef ORC_RC_EVAL
         }
     }
+    stat_enter(oldcat);
 }
 
 void orc_cull_unobservable(float *pred, int pw, int ph, const float *obs, int ow, int oh) {
@@ -698,6 +717,7 @@ int orc_ne_mod2obs(const float *pred, int width, int height, int modelNum, const
     float *de = (float *)malloc(sizeof(float) * (size_t)(fullDims + dims));
     float *Jr = de + fullDims;
     int numPredictions = 0;
+    const int oldcat = stat_enter(ORC_STAT_NE_MOD2OBS);
     for (int index = 0; index < width * height; ++index) {
         const float *pc = pred + 4 * index;
         if (pc[2] == 0) continue;
@@ -720,6 +740,7 @@ int orc_ne_mod2obs(const float *pred, int width, int height, int modelNum, const
         ++numPredictions;
         sys_add_squared(&s, residual, J);
     }
+    stat_enter(oldcat);
     free(de);
     sys_emit(&s, result);
     return numPredictions;
