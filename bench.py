@@ -183,7 +183,7 @@ def main():
                        "iterations_per_step": iters, "frames_per_gpu": 1, "parallelism": "independent frames, 1 per GPU"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(line))
+        print(json.dumps(line, default=float))
     if distributed:
         dist.destroy_process_group()
 

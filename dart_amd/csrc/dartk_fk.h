@@ -48,37 +48,64 @@ __device__ inline void se3_exp(const float *p, float *out) {   // SE3Fromse3, SE
     out[8] = a * -wy + b * (wx * wz);      out[9] = a * wx + b * (wy * wz);       out[10] = 1 + b * (-wy * wy - wx * wx); out[11] = tz;
 }
 
-// mode 0: setPose (GraspIt DH), 1: setArticulation (axis-angle)
-__device__ inline void fk_device(const ModelView &m, int mode) {
-    float *T_mf = m.T_mf, *T_fm = m.T_fm;
-    const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    for (int i = 0; i < 12; ++i) { T_mf[i] = I[i]; T_fm[i] = I[i]; }
-    for (int f = 1; f < m.nFrames; ++f) {
-        const int joint = f - 1;
-        const float p = fminf(fmaxf(m.limits[2 * joint], m.joints[joint]), m.limits[2 * joint + 1]);
-        const float ax = m.jointAxis[3 * joint], ay = m.jointAxis[3 * joint + 1], az = m.jointAxis[3 * joint + 2];
-        float D[12], T[12], P[12];
-        if (mode == 0) {
-            const float *dh = m.dh + 4 * joint;
-            if (m.jointType[joint] == 0) dh_graspit(dh[3] + p * az, dh[2], dh[0], dh[1] + p * ax, p * ay, D);
-            else                         dh_graspit(dh[3], dh[2] + p * az, dh[0] + p * ax, dh[1], p * ay, D);
-        } else {
-            float t6[6] = {0, 0, 0, 0, 0, 0};
-            if (m.jointType[joint] == 0) { t6[3] = p * ax; t6[4] = p * ay; t6[5] = p * az; }
-            else                         { t6[0] = p * ax; t6[1] = p * ay; t6[2] = p * az; }
-            se3_exp(t6, D);
-        }
-        for (int i = 0; i < 12; ++i) P[i] = m.T_pf[12 * joint + i];
-        se3_mul(P, D, T);
-        float parentT[12];
-        for (int i = 0; i < 12; ++i) parentT[i] = T_mf[12 * m.frameParent[f] + i];
-        float R[12], Rinv[12];
-        se3_mul(parentT, T, R);
-        se3_invert(R, Rinv);
-        for (int i = 0; i < 12; ++i) { T_mf[12 * f + i] = R[i]; T_fm[12 * f + i] = Rinv[i]; }
+// Local transform of joint `joint` (frame joint+1) relative to its parent frame: T_pf * D(p).
+// mode 0: setPose (GraspIt DH form, mirrored_model.cpp:196-213), 1: setArticulation (axis-angle, :165-166)
+__device__ inline void fk_local(const ModelView &m, int mode, int joint, float *T) {
+    const float p = fminf(fmaxf(m.limits[2 * joint], m.joints[joint]), m.limits[2 * joint + 1]);
+    const float ax = m.jointAxis[3 * joint], ay = m.jointAxis[3 * joint + 1], az = m.jointAxis[3 * joint + 2];
+    float D[12], P[12];
+    if (mode == 0) {
+        const float *dh = m.dh + 4 * joint;
+        if (m.jointType[joint] == 0) dh_graspit(dh[3] + p * az, dh[2], dh[0], dh[1] + p * ax, p * ay, D);
+        else                         dh_graspit(dh[3], dh[2] + p * az, dh[0] + p * ax, dh[1], p * ay, D);
+    } else {
+        float t6[6] = {0, 0, 0, 0, 0, 0};
+        if (m.jointType[joint] == 0) { t6[3] = p * ax; t6[4] = p * ay; t6[5] = p * az; }
+        else                         { t6[0] = p * ax; t6[1] = p * ay; t6[2] = p * az; }
+        se3_exp(t6, D);
     }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) P[i] = m.T_pf[12 * joint + i];
+    se3_mul(P, D, T);
 }
 
+// Forward kinematics by ONE wave (call with all 64 lanes of a wave; nFrames <= 65). Lane j owns joint j /
+// frame j+1: the trigonometry of all joints runs in parallel, then the chain products T_mf[f] = T_mf[parent]*T
+// are resolved level by level of the kinematic tree (depth <= 5 for the hands). Per frame the arithmetic is the
+// same sequence as the serial walk of the reference (mirrored_model.cpp:185-225), so results are identical.
+// `sT` = LDS scratch of 12*nFrames floats.
+__device__ inline void fk_wave(const ModelView &m, int mode, float *sT) {
+    const int lane = threadIdx.x & 63;
+    const int f = lane + 1;
+    const bool mine = f < m.nFrames;
+    float T[12];
+    int depth = 0, parent = 0;
+    if (mine) {
+        fk_local(m, mode, lane, T);
+        parent = m.frameParent[f];
+        for (int q = f; q != 0; q = m.frameParent[q]) ++depth;
+    }
+    if (lane == 0) {
+        const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { sT[i] = I[i]; m.T_mf[i] = I[i]; m.T_fm[i] = I[i]; }
+    }
+    int maxDepth = depth;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxDepth = max(maxDepth, __shfl_xor(maxDepth, o));
+    for (int level = 1; level <= maxDepth; ++level) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous level's LDS writes have landed
+        if (mine && depth == level) {
+            float P[12], R[12], Rinv[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) P[i] = sT[12 * parent + i];
+            se3_mul(P, T, R);
+            se3_invert(R, Rinv);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { sT[12 * f + i] = R[i]; m.T_mf[12 * f + i] = R[i]; m.T_fm[12 * f + i] = Rinv[i]; }
+        }
+    }
+}
 
 #endif  // __HIPCC__
 

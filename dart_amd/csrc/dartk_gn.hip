@@ -121,10 +121,50 @@ fused_obs2mod_kernel(const float4 *__restrict__ vert, const float4 *__restrict__
 // -----------------------------------------------------------------------------------------------------
 // reduce + assemble + solve + update (optimizer.cpp:462-518), one workgroup.
 // -----------------------------------------------------------------------------------------------------
+// One term of the normal equations: per-workgroup partial systems -> one packed system.
+struct ReduceTerm {
+    const float *slabs; int nBlocks; int S;
+    const int *count; int minCount;      // system kept only if *count > minCount (obsToMod.cu:646); count may be null
+    float *out;
+};
+struct ReduceArgs { ReduceTerm t[4]; };
+
+// Fixed-order fp64 sum of the partial systems, spread over the chip: workgroup (x, term) owns 64 outputs of one
+// term; its 4 waves each sum a quarter of the slabs and the quarters are combined in a fixed order. Bitwise
+// reproducible (no atomics), ~1/4 MB read by ~15 workgroups instead of by one.
+__global__ void __launch_bounds__(256)
+gn_reduce_kernel(ReduceArgs a) {
+    __shared__ double part[4][64];
+    const ReduceTerm t = a.t[blockIdx.y];
+    const int o = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int q = threadIdx.x >> 6;
+    if (blockIdx.x * 64 >= t.S) return;
+    const bool keep = t.slabs && (!t.count || *t.count > t.minCount);
+    double s = 0.0;
+    if (keep && o < t.S) {
+        const int per = (t.nBlocks + 3) >> 2;
+        const int b0 = q * per, b1 = min(t.nBlocks, b0 + per);
+        const float *p = t.slabs + (size_t)b0 * t.S + o;
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p[(size_t)k * t.S];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += (double)v[k];
+            p += (size_t)8 * t.S;
+        }
+        for (; b < b1; ++b) { s += (double)*p; p += t.S; }
+    }
+    part[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && o < t.S) t.out[o] = (float)(((part[0][o & 63] + part[1][o & 63]) + part[2][o & 63]) + part[3][o & 63]);
+}
+
 struct SolveArgs {
-    const float *slabsA; int nBlocksA; const int *countA;     // obs->mod
-    const float *slabsB; int nBlocksB; const int *countB;     // mod->obs
-    const float *slabsC; int nBlocksC;                        // self-intersection (articulation-only system)
+    const float *sysA; int *countA;     // obs->mod (reduced packed systems, see gn_reduce_kernel)
+    const float *sysB; int *countB;     // mod->obs
+    const float *sysC;                  // self-intersection (articulation-only system)
     float lambdaA, lambdaB, lambdaC;
     float regularization, lmLambda;
     float *iterInfo;        // 8 floats or null
@@ -199,51 +239,35 @@ __device__ void ldlt_solve_wave(float *A, int ld, int n, const float *b, float *
     wave_sync();
 }
 
-__global__ void __launch_bounds__(256)
+// assemble + solve + update + forward kinematics (optimizer.cpp:482-518), ONE wave.
+__global__ void __launch_bounds__(64)
 gn_solve_single_kernel(ModelView m, SolveArgs a) {
     extern __shared__ float lds[];
     const int d = 6 + m.nJoints;
     const int ad = d - 6;
     const int S = sys_size(d), Sa = sys_size(ad);
     const int ld = d + 1;
-    float *sysA = lds;
-    float *sysB = sysA + S;
-    float *sysC = sysB + S;
-    float *JTJ = sysC + S;                  // [d][ld]
+    float *JTJ = lds;                       // [d][ld]
     float *eJ = JTJ + d * ld;
     float *x = eJ + d;
     float *y = x + d;
     int *perm = reinterpret_cast<int *>(y + d);
+    float *sT = reinterpret_cast<float *>(perm + d);      // forward-kinematics scratch, 12*nFrames
     const int tid = threadIdx.x;
+    const float *__restrict__ sysA = a.sysA, *__restrict__ sysB = a.sysB, *__restrict__ sysC = a.sysC;
 
-    // 1. fixed-order fp64 reduction of the per-workgroup partial systems
-    const bool keepA = a.slabsA && (*a.countA > 10);      // obsToMod.cu:646
-    for (int o = tid; o < S; o += blockDim.x) {
-        double s = 0.0;
-        if (keepA) for (int b = 0; b < a.nBlocksA; ++b) s += (double)a.slabsA[(size_t)b * S + o];
-        sysA[o] = (float)s;
-        s = 0.0;
-        if (a.slabsB) for (int b = 0; b < a.nBlocksB; ++b) s += (double)a.slabsB[(size_t)b * S + o];
-        sysB[o] = (float)s;
-    }
-    for (int o = tid; o < Sa; o += blockDim.x) {
-        double s = 0.0;
-        if (a.slabsC) for (int b = 0; b < a.nBlocksC; ++b) s += (double)a.slabsC[(size_t)b * Sa + o];
-        sysC[o] = (float)s;
-    }
-    __syncthreads();
     if (a.firstSystem) {
-        for (int o = tid; o < S; o += blockDim.x) { a.firstSystem[o] = sysA[o]; a.firstSystem[S + o] = sysB[o]; }
-        for (int o = tid; o < Sa; o += blockDim.x) a.firstSystem[2 * S + o] = sysC[o];
+        for (int o = tid; o < S; o += 64) { a.firstSystem[o] = sysA ? sysA[o] : 0.0f; a.firstSystem[S + o] = sysB ? sysB[o] : 0.0f; }
+        for (int o = tid; o < Sa; o += 64) a.firstSystem[2 * S + o] = sysC ? sysC[o] : 0.0f;
     }
-    // 2. unpack (optimizer.cpp:50-70) in the reference's term order, symmetrise, regularise, LM-scale
-    for (int idx = tid; idx < d * d; idx += blockDim.x) {
+    // unpack (optimizer.cpp:50-70) in the reference's term order, symmetrise, regularise, LM-scale
+    for (int idx = tid; idx < d * d; idx += 64) {
         const int i = idx / d, j = idx % d;
         const int lo = i < j ? i : j, hi = i < j ? j : i;          // upper (lo,hi) <- packed[hi(hi+1)/2 + lo]
         float v = 0.0f;
-        if (a.slabsA) v += a.lambdaA * sysA[d + ((hi * (hi + 1)) >> 1) + lo];
-        if (a.slabsB) v += a.lambdaB * sysB[d + ((hi * (hi + 1)) >> 1) + lo];
-        if (a.slabsC && lo >= 6) {
+        if (sysA) v += a.lambdaA * sysA[d + ((hi * (hi + 1)) >> 1) + lo];
+        if (sysB) v += a.lambdaB * sysB[d + ((hi * (hi + 1)) >> 1) + lo];
+        if (sysC && lo >= 6) {
             const int p = lo - 6, q = hi - 6;
             float t = 0.0f;
             t += a.lambdaC * sysC[ad + ((q * (q + 1)) >> 1) + p];
@@ -252,47 +276,45 @@ gn_solve_single_kernel(ModelView m, SolveArgs a) {
         if (i == j) { v += a.regularization * 1.0f; v += a.lmLambda * v; }
         JTJ[i * ld + j] = v;
     }
-    for (int j = tid; j < d; j += blockDim.x) {
+    for (int j = tid; j < d; j += 64) {
         float v = 0.0f;
-        if (a.slabsA) v += a.lambdaA * sysA[j];
-        if (a.slabsB) v += a.lambdaB * sysB[j];
-        if (a.slabsC && j >= 6) { float t = 0.0f; t += a.lambdaC * sysC[j - 6]; v += t; }
+        if (sysA) v += a.lambdaA * sysA[j];
+        if (sysB) v += a.lambdaB * sysB[j];
+        if (sysC && j >= 6) { float t = 0.0f; t += a.lambdaC * sysC[j - 6]; v += t; }
         eJ[j] = v;
     }
-    if (tid == 0 && a.iterInfo) {
-        a.iterInfo[0] = a.slabsA ? a.lambdaA * sysA[S - 1] : 0.0f;
-        a.iterInfo[1] = a.slabsB ? a.lambdaB * sysB[S - 1] : 0.0f;
-        a.iterInfo[2] = a.slabsC ? a.lambdaC * sysC[Sa - 1] : 0.0f;
-        a.iterInfo[3] = a.slabsA ? (float)*a.countA : 0.0f;
-        a.iterInfo[4] = a.slabsB ? (float)*a.countB : 0.0f;
-        a.iterInfo[5] = a.iterInfo[6] = a.iterInfo[7] = 0.0f;
-    }
-    __syncthreads();
-    // 3. solve + update by wave 0
-    if (tid < 64) {
-        ldlt_solve_wave(JTJ, ld, d, eJ, x, perm, y);
-        if (tid == 0) {
-            float t6[6], dT[12], T[12], Tn[12], Tinv[12];
-            for (int i = 0; i < 6; ++i) t6[i] = -x[i];
-            se3_exp(t6, dT);
-            for (int i = 0; i < 12; ++i) T[i] = m.T_mc[i];
-            se3_mul(dT, T, Tn);
-            se3_invert(Tn, Tinv);
-            for (int i = 0; i < 12; ++i) { m.T_mc[i] = Tn[i]; m.T_cm[i] = Tinv[i]; }
+    if (tid == 0) {
+        if (a.iterInfo) {
+            a.iterInfo[0] = sysA ? a.lambdaA * sysA[S - 1] : 0.0f;
+            a.iterInfo[1] = sysB ? a.lambdaB * sysB[S - 1] : 0.0f;
+            a.iterInfo[2] = sysC ? a.lambdaC * sysC[Sa - 1] : 0.0f;
+            a.iterInfo[3] = sysA ? (float)*a.countA : 0.0f;
+            a.iterInfo[4] = sysB ? (float)*a.countB : 0.0f;
+            a.iterInfo[5] = a.iterInfo[6] = a.iterInfo[7] = 0.0f;
         }
-        for (int i = tid; i < m.nJoints; i += 64) {
-            const float v = m.joints[i] + (-x[6 + i]);
-            m.joints[i] = fminf(fmaxf(m.limits[2 * i], v), m.limits[2 * i + 1]);
-        }
+        *a.countA = 0; *a.countB = 0;       // ready for the next iteration's kernels (stream order)
     }
-    __syncthreads();
-    // 4. forward kinematics for the next iteration (MirroredModel::setPose)
-    if (tid == 0) fk_device(m, 0);
+    wave_sync();
+    ldlt_solve_wave(JTJ, ld, d, eJ, x, perm, y);
+    if (tid == 0) {
+        float t6[6], dT[12], T[12], Tn[12], Tinv[12];
+        for (int i = 0; i < 6; ++i) t6[i] = -x[i];
+        se3_exp(t6, dT);
+        for (int i = 0; i < 12; ++i) T[i] = m.T_mc[i];
+        se3_mul(dT, T, Tn);
+        se3_invert(Tn, Tinv);
+        for (int i = 0; i < 12; ++i) { m.T_mc[i] = Tn[i]; m.T_cm[i] = Tinv[i]; }
+    }
+    if (tid < m.nJoints) {
+        const float v = m.joints[tid] + (-x[6 + tid]);
+        m.joints[tid] = fminf(fmaxf(m.limits[2 * tid], v), m.limits[2 * tid + 1]);
+    }
+    // forward kinematics for the next iteration (MirroredModel::setPose); lane j re-reads the joint it just wrote
+    fk_wave(m, 0, sT);
 }
 
-static size_t solve_lds_bytes(int d) {
-    const int S = sys_size(d);
-    return sizeof(float) * (size_t)(3 * S + d * (d + 1) + 4 * d + 8);
+static size_t solve_lds_bytes(int d, int nFrames) {
+    return sizeof(float) * (size_t)(d * (d + 1) + 4 * d + 12 * nFrames + 8);
 }
 
 }  // namespace dartk
@@ -351,6 +373,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     float *slabsA = ws->partials, *slabsB = slabsA + (size_t)GN_MAX_BLOCKS * S, *slabsC = slabsB + (size_t)GN_MAX_BLOCKS * S;
     int *cntA = ws->counters, *cntB = ws->counters + 1;
     float *d_T_gc = ws->sysScratch + 128;      // camera -> obs-SDF frame, frozen at the start (optimizer.cpp:446-448)
+    float *sysA = ws->sysScratch + kMaxSys, *sysB = sysA + kMaxSys, *sysC = sysB + kMaxSys;   // reduced packed systems
 
     const int nPix = width * height;
     const int tilesA = (nPix + NE_BLOCK - 1) / NE_BLOCK;
@@ -370,11 +393,12 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         DARTK_HIP(hipMemcpyAsync(d_T_gc, m.T_mc, 12 * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     const size_t ldsA = sizeof(float) * (24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8);
-    const size_t ldsS = solve_lds_bytes(d);
+    const size_t ldsS = solve_lds_bytes(d, m.nFrames);
     DARTK_REQUIRE(ldsA <= 160 * 1024 && ldsS <= 160 * 1024, "LDS requirement exceeds 160 KiB");
     if (ldsS > 64 * 1024)
         DARTK_HIP(hipFuncSetAttribute((const void *)gn_solve_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS));
 
+    DARTK_HIP(hipMemsetAsync(ws->counters, 0, 2 * sizeof(int), st));      // later iterations: zeroed by the solve kernel
     for (int it = 0; it < o->numIterations; ++it) {
         if (useB) {
             ProfScope ps(DARTK_PROF_RAYCAST, st);
@@ -382,7 +406,6 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
                                    o->predWidth, o->predHeight, 0, m, d_prediction, st);
             if (rc) return rc;
         }
-        DARTK_HIP(hipMemsetAsync(ws->counters, 0, 2 * sizeof(int), st));
         if (useA) {
             ProfScope ps(DARTK_PROF_FUSED_OBS2MOD, st);
 #define DARTK_LAUNCH_FUSED(PPT_)                                                                                \
@@ -410,17 +433,24 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
             rc = gn_launch_ne_self(d_cloud, nCloud, m, d_potential, slabsC, nBlocksC, st);
             if (rc) return rc;
         }
+        const int Sa = sys_size(d - 6);
+        ReduceArgs ra = {};
+        int nTerms = 0;
+        if (useA) ra.t[nTerms++] = ReduceTerm{slabsA, nBlocksA, S, cntA, 10, sysA};
+        if (useB) ra.t[nTerms++] = ReduceTerm{slabsB, nBlocksB, S, nullptr, 0, sysB};
+        if (useC) ra.t[nTerms++] = ReduceTerm{slabsC, nBlocksC, Sa, nullptr, 0, sysC};
         SolveArgs a;
-        a.slabsA = useA ? slabsA : nullptr; a.nBlocksA = nBlocksA; a.countA = cntA;
-        a.slabsB = useB ? slabsB : nullptr; a.nBlocksB = nBlocksB; a.countB = cntB;
-        a.slabsC = useC ? slabsC : nullptr; a.nBlocksC = nBlocksC;
+        a.sysA = useA ? sysA : nullptr; a.countA = cntA;
+        a.sysB = useB ? sysB : nullptr; a.countB = cntB;
+        a.sysC = useC ? sysC : nullptr;
         a.lambdaA = o->lambdaObsToMod; a.lambdaB = o->lambdaModToObs; a.lambdaC = o->lambdaIntersection;
         a.regularization = o->regularization; a.lmLambda = o->regularizationScaled;
         a.iterInfo = d_iterInfo ? d_iterInfo + 8 * it : nullptr;
         a.firstSystem = (it == 0) ? d_firstSystem : nullptr;
         {
             ProfScope ps(DARTK_PROF_SOLVE, st);
-            hipLaunchKernelGGL(gn_solve_single_kernel, dim3(1), dim3(256), ldsS, st, m, a);
+            if (nTerms) hipLaunchKernelGGL(gn_reduce_kernel, dim3((S + 63) / 64, nTerms), dim3(256), 0, st, ra);
+            hipLaunchKernelGGL(gn_solve_single_kernel, dim3(1), dim3(64), ldsS, st, m, a);
         }
         DARTK_HIP(hipGetLastError());
     }

@@ -9,34 +9,34 @@
 namespace dartk {
 
 // -----------------------------------------------------------------------------------------------------
-// ray-cast prediction (raycast.cu:121-215). One lane per prediction pixel; the per-SDF camera<->frame
-// transforms are composed once per workgroup into LDS (lane s does SDF s) instead of once per lane per SDF.
+// ray-cast prediction (raycast.cu:121-215). The reference walks one ray per thread through every SDF in turn,
+// a serial chain of ~nSdfs sphere-traces whose only coupling is the running closest hit. Here a workgroup owns an
+// 8x8 pixel tile and its 4 waves trace 4 SDFs at a time for the same 64 rays (lane = ray, wave = SDF): each
+// (ray, SDF) trace records the step position at which its first zero crossing was DETECTED and the refined hit;
+// wave 0 then replays the reference's sequential rule in SDF order -- a crossing counts iff its detection step
+// lies before the closest hit so far (the reference's `t0 < closestT` loop test) -- so the map is identical to
+// the serial walk. Traces of later rounds are cut at the closest hit of the earlier rounds (the reference's
+// pruning, one round coarser). Per-SDF camera<->frame transforms are composed once per workgroup into LDS.
 // -----------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+static constexpr int RC_WAVES = 4;
+__global__ void __launch_bounds__(64 * RC_WAVES)
 raycast_prediction_kernel(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, ModelView m,
                           float4 *__restrict__ prediction, float levelSet) {
-    extern __shared__ float lds[];     // [nSdfs][24]: T_fc then T_cf
-    for (int s = threadIdx.x; s < m.nSdfs; s += blockDim.x) {
-        const int f = m.sdfFrame[s];
-        float T_fm[12], T_mf[12], T_mc[12], T_cm[12], T_fc[12], T_cf[12];
-        for (int i = 0; i < 12; ++i) { T_fm[i] = m.T_fm[12 * f + i]; T_mf[i] = m.T_mf[12 * f + i]; T_mc[i] = m.T_mc[i]; }
-        se3_invert(T_mc, T_cm);                 // raycast.cu:143
-        se3_mul(T_fm, T_mc, T_fc);              // T_fms[f]*T_mc
-        se3_mul(T_cm, T_mf, T_cf);              // T_cm*T_mfs[f]
-        for (int i = 0; i < 12; ++i) { lds[24 * s + i] = T_fc[i]; lds[24 * s + 12 + i] = T_cf[i]; }
-    }
-    __syncthreads();
-    // 8x8 pixel tiles, 4 tiles per 256-lane workgroup (tile = wave): neighbouring rays march together
+    __shared__ float sT[RC_WAVES * 24];        // per SDF of the round: T_fc then T_cf
+    __shared__ float sDet[RC_WAVES * 64];
+    __shared__ float sHit[RC_WAVES * 64];
+    __shared__ float sClosest[64];
     const int tilesX = (width + 7) >> 3;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int x = (tile % tilesX) * 8 + (lane & 7);
-    const int y = (tile / tilesX) * 8 + (lane >> 3);
-    if (x >= width || y >= height) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = (blockIdx.x % tilesX) * 8 + (lane & 7);
+    const int y = (blockIdx.x / tilesX) * 8 + (lane >> 3);
+    const bool valid = x < width && y < height;
     const int index = x + y * width;
-    float4 pr = prediction[index];
-    if (modelNum == 0) { pr.z = 0; pr.w = -1; }
-
+    float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wave == 0 && valid) {
+        pr = prediction[index];
+        if (modelNum == 0) { pr.z = 0; pr.w = -1; }
+    }
     const float invflx = 1.0f / flx, invfly = 1.0f / fly;
     const float uvx = (float)((double)x + 0.5), uvy = (float)((double)y + 0.5);
     f3 rd; rd.x = (uvx - ppx) * invflx; rd.y = (uvy - ppy) * invfly; rd.z = 1.0f;
@@ -45,62 +45,97 @@ raycast_prediction_kernel(float flx, float fly, float ppx, float ppy, int width,
         rd.x *= inv; rd.y *= inv; rd.z *= inv;
     }
     float closestT = 10000;
-    for (int s = 0; s < m.nSdfs; ++s) {
-        const SdfDev &sdf = m.sdfs[s];
-        const float *T_fc = lds + 24 * s;
-        const f3 of = se3_apply_w(T_fc, 0.f, 0.f, 0.f, 1.f);
-        const f3 df = se3_apply_w(T_fc, rd.x, rd.y, rd.z, 0.f);
-        f3 dn;
-        {
-            const float inv = 1.0f / sqrtf(df.x * df.x + df.y * df.y + df.z * df.z);
-            dn.x = df.x * inv; dn.y = df.y * inv; dn.z = df.z * inv;
+    if (wave == 0) sClosest[lane] = closestT;
+    const int nSdfs = m.nSdfs;
+    for (int s0 = 0; s0 < nSdfs; s0 += RC_WAVES) {
+        const int nc = min(RC_WAVES, nSdfs - s0);
+        __syncthreads();                        // previous round's replay is finished with sT / sDet / sHit
+        if (threadIdx.x < nc) {
+            const int f = m.sdfFrame[s0 + threadIdx.x];
+            float T_fm[12], T_mf[12], T_mc[12], T_cm[12], T_fc[12], T_cf[12];
+            for (int i = 0; i < 12; ++i) { T_fm[i] = m.T_fm[12 * f + i]; T_mf[i] = m.T_mf[12 * f + i]; T_mc[i] = m.T_mc[i]; }
+            se3_invert(T_mc, T_cm);                 // raycast.cu:143
+            se3_mul(T_fm, T_mc, T_fc);              // T_fms[f]*T_mc
+            se3_mul(T_cm, T_mf, T_cf);              // T_cm*T_mfs[f]
+            for (int i = 0; i < 12; ++i) { sT[24 * threadIdx.x + i] = T_fc[i]; sT[24 * threadIdx.x + 12 + i] = T_cf[i]; }
         }
-        const float sminx = sdf.ox, sminy = sdf.oy, sminz = sdf.oz;
-        const float smaxx = sdf.ox + sdf.res * (float)(unsigned)sdf.dimx;
-        const float smaxy = sdf.oy + sdf.res * (float)(unsigned)sdf.dimy;
-        const float smaxz = sdf.oz + sdf.res * (float)(unsigned)sdf.dimz;
-        const float hix = (float)((unsigned)sdf.dimx - 2u), hiy = (float)((unsigned)sdf.dimy - 2u), hiz = (float)((unsigned)sdf.dimz - 2u);
-        // intersectBox, raycast.cu:11-35
-        float t0, t1;
-        {
-            const float ix = 1.0f / dn.x, iy = 1.0f / dn.y, iz = 1.0f / dn.z;
-            const float bx = ix * (sminx - of.x), by = iy * (sminy - of.y), bz = iz * (sminz - of.z);
-            const float tx = ix * (smaxx - of.x), ty = iy * (smaxy - of.y), tz = iz * (smaxz - of.z);
-            const float mnx = fminf(tx, bx), mny = fminf(ty, by), mnz = fminf(tz, bz);
-            const float mxx = fmaxf(tx, bx), mxy = fmaxf(ty, by), mxz = fmaxf(tz, bz);
-            t0 = fmaxf(fmaxf(mnx, mny), mnz);
-            t1 = fminf(fminf(mxx, mxy), mxz);
-        }
-        if (!(t1 > t0)) continue;
-        const float *data = m.grids + sdf.dataOff;
-        auto eval = [&](float tt) -> float {
-            f3 xf, xg;
-            xf.x = dn.x * tt + of.x; xf.y = dn.y * tt + of.y; xf.z = dn.z * tt + of.z;
-            xg.x = fmaxf(1.0f, fminf((xf.x - sdf.ox) / sdf.res, hix));
-            xg.y = fmaxf(1.0f, fminf((xf.y - sdf.oy) / sdf.res, hiy));
-            xg.z = fmaxf(1.0f, fminf((xf.z - sdf.oz) / sdf.res, hiz));
-            return grid_value(data, sdf.dimx, sdf.dimy, xg) * sdf.res;
-        };
-        float sdfVal = eval(t0);
-        float sdfValPrev = sdfVal;
-        float tPrev = t0;
-        const float minStep = sdf.res / 10;
-        while (t0 < t1 && t0 < closestT) {
-            sdfVal = eval(t0);
-            if (sdfValPrev > levelSet && sdfVal <= levelSet) {
-                const float tHit = (t0 - tPrev) * (levelSet - sdfValPrev) / (sdfVal - sdfValPrev) + tPrev;
-                const f3 xc = se3_apply_w(lds + 24 * s + 12, dn.x * tHit + of.x, dn.y * tHit + of.y, dn.z * tHit + of.z, 1.0f);
-                if (pr.z == 0 || xc.z < pr.z) {
-                    pr.x = xc.x; pr.y = xc.y; pr.z = xc.z; pr.w = (float)((modelNum << 16) + s);
+        __syncthreads();
+        if (wave < nc) {
+            float det = 3.0e38f, hit = 0.0f;
+            if (valid) {
+                const float limitT = sClosest[lane];
+                const SdfDev &sdf = m.sdfs[s0 + wave];
+                const float *T_fc = sT + 24 * wave;
+                const f3 of = se3_apply_w(T_fc, 0.f, 0.f, 0.f, 1.f);
+                const f3 df = se3_apply_w(T_fc, rd.x, rd.y, rd.z, 0.f);
+                f3 dn;
+                {
+                    const float inv = 1.0f / sqrtf(df.x * df.x + df.y * df.y + df.z * df.z);
+                    dn.x = df.x * inv; dn.y = df.y * inv; dn.z = df.z * inv;
                 }
-                closestT = tHit;
+                const float smaxx = sdf.ox + sdf.res * (float)(unsigned)sdf.dimx;
+                const float smaxy = sdf.oy + sdf.res * (float)(unsigned)sdf.dimy;
+                const float smaxz = sdf.oz + sdf.res * (float)(unsigned)sdf.dimz;
+                const float hix = (float)((unsigned)sdf.dimx - 2u), hiy = (float)((unsigned)sdf.dimy - 2u), hiz = (float)((unsigned)sdf.dimz - 2u);
+                float t0, t1;   // intersectBox, raycast.cu:11-35
+                {
+                    const float ix = 1.0f / dn.x, iy = 1.0f / dn.y, iz = 1.0f / dn.z;
+                    const float bx = ix * (sdf.ox - of.x), by = iy * (sdf.oy - of.y), bz = iz * (sdf.oz - of.z);
+                    const float tx = ix * (smaxx - of.x), ty = iy * (smaxy - of.y), tz = iz * (smaxz - of.z);
+                    t0 = fmaxf(fmaxf(fminf(tx, bx), fminf(ty, by)), fminf(tz, bz));
+                    t1 = fminf(fminf(fmaxf(tx, bx), fmaxf(ty, by)), fmaxf(tz, bz));
+                }
+                if (t1 > t0) {
+                    const float *data = m.grids + sdf.dataOff;
+                    auto eval = [&](float tt) -> float {
+                        f3 xf, xg;
+                        xf.x = dn.x * tt + of.x; xf.y = dn.y * tt + of.y; xf.z = dn.z * tt + of.z;
+                        xg.x = fmaxf(1.0f, fminf((xf.x - sdf.ox) / sdf.res, hix));
+                        xg.y = fmaxf(1.0f, fminf((xf.y - sdf.oy) / sdf.res, hiy));
+                        xg.z = fmaxf(1.0f, fminf((xf.z - sdf.oz) / sdf.res, hiz));
+                        return grid_value(data, sdf.dimx, sdf.dimy, xg) * sdf.res;
+                    };
+                    float sdfValPrev = eval(t0);
+                    float tPrev = t0;
+                    const float minStep = sdf.res / 10;
+                    while (t0 < t1 && t0 < limitT) {
+                        const float sdfVal = eval(t0);
+                        if (sdfValPrev > levelSet && sdfVal <= levelSet) {
+                            det = t0;
+                            hit = (t0 - tPrev) * (levelSet - sdfValPrev) / (sdfVal - sdfValPrev) + tPrev;
+                            break;                  // the reference's loop ends here too: closestT = hit <= t0 < next t0
+                        }
+                        sdfValPrev = sdfVal;
+                        tPrev = t0;
+                        t0 += fmaxf(minStep, fabsf(sdfVal));
+                    }
+                }
             }
-            sdfValPrev = sdfVal;
-            tPrev = t0;
-            t0 += fmaxf(minStep, fabsf(sdfVal));
+            sDet[wave * 64 + lane] = det;
+            sHit[wave * 64 + lane] = hit;
+        }
+        __syncthreads();
+        if (wave == 0 && valid) {       // sequential rule of the reference over this round's SDFs
+            for (int k = 0; k < nc; ++k) {
+                const float det = sDet[k * 64 + lane];
+                if (det < closestT) {
+                    const float tHit = sHit[k * 64 + lane];
+                    const float *T_fc = sT + 24 * k;
+                    const f3 of = se3_apply_w(T_fc, 0.f, 0.f, 0.f, 1.f);
+                    const f3 df = se3_apply_w(T_fc, rd.x, rd.y, rd.z, 0.f);
+                    const float inv = 1.0f / sqrtf(df.x * df.x + df.y * df.y + df.z * df.z);
+                    const float dnx = df.x * inv, dny = df.y * inv, dnz = df.z * inv;
+                    const f3 xc = se3_apply_w(T_fc + 12, dnx * tHit + of.x, dny * tHit + of.y, dnz * tHit + of.z, 1.0f);
+                    if (pr.z == 0 || xc.z < pr.z) {
+                        pr.x = xc.x; pr.y = xc.y; pr.z = xc.z; pr.w = (float)((modelNum << 16) + s0 + k);
+                    }
+                    closestT = tHit;
+                }
+            }
+            sClosest[lane] = closestT;
         }
     }
-    prediction[index] = pr;
+    if (wave == 0 && valid) prediction[index] = pr;
 }
 
 // gpu_cullUnobservable, modToObs.cu:682-709
@@ -157,6 +192,7 @@ dt_pass_x_kernel(const float *__restrict__ in, float *__restrict__ out, int len,
         const int l = i / len, q = i - l * len;
         const float *row = lds + l * len;
         float best = 3.0e38f;
+#pragma unroll 8
         for (int p = 0; p < len; ++p) {
             const int d = q - p;
             best = fminf(best, (float)(d * d) + row[p]);
@@ -164,14 +200,19 @@ dt_pass_x_kernel(const float *__restrict__ in, float *__restrict__ out, int len,
         out[(size_t)line0 * len + i] = takeSqrt ? sqrtf(best) : best;
     }
 }
-// along a strided axis: workgroup = 64 consecutive x by the whole line; lanes (x, q-group)
+// along a strided axis: workgroup = 64 consecutive x by the whole line in LDS, producing DT_QCHUNK outputs of it;
+// lane (x, group) computes 4 outputs that share every LDS read. grid = tilesX * nOuter * ceil(len/DT_QCHUNK).
+static constexpr int DT_QCHUNK = 16;
 __global__ void __launch_bounds__(256)
 dt_pass_strided_kernel(const float *__restrict__ in, float *__restrict__ out, int len, int stride, int width, int nOuter,
                        int outerStride, int takeSqrt) {
     extern __shared__ float lds[];      // [len][64]
     const int tilesX = (width + 63) / 64;
-    const int x0 = (blockIdx.x % tilesX) * 64;
-    const int outer = blockIdx.x / tilesX;
+    const int qChunks = (len + DT_QCHUNK - 1) / DT_QCHUNK;
+    const int qc = blockIdx.x % qChunks;
+    const int rest = blockIdx.x / qChunks;
+    const int x0 = (rest % tilesX) * 64;
+    const int outer = rest / tilesX;
     if (outer >= nOuter) return;
     const int lx = threadIdx.x & 63, g = threadIdx.x >> 6;
     const size_t base = (size_t)outer * outerStride + x0 + lx;
@@ -179,14 +220,21 @@ dt_pass_strided_kernel(const float *__restrict__ in, float *__restrict__ out, in
     for (int p = g; p < len; p += 4) lds[p * 64 + lx] = ok ? in[base + (size_t)p * stride] : 3.0e38f;
     __syncthreads();
     if (!ok) return;
-    for (int q = g; q < len; q += 4) {
-        float best = 3.0e38f;
-        for (int p = 0; p < len; ++p) {
-            const int d = q - p;
-            best = fminf(best, (float)(d * d) + lds[p * 64 + lx]);
-        }
-        out[base + (size_t)q * stride] = takeSqrt ? sqrtf(best) : best;
+    const int q0 = qc * DT_QCHUNK + g * 4;
+    float b0 = 3.0e38f, b1 = 3.0e38f, b2 = 3.0e38f, b3 = 3.0e38f;
+#pragma unroll 8
+    for (int p = 0; p < len; ++p) {
+        const float v = lds[p * 64 + lx];
+        const int d0 = q0 - p, d1 = q0 + 1 - p, d2 = q0 + 2 - p, d3 = q0 + 3 - p;
+        b0 = fminf(b0, (float)(d0 * d0) + v);
+        b1 = fminf(b1, (float)(d1 * d1) + v);
+        b2 = fminf(b2, (float)(d2 * d2) + v);
+        b3 = fminf(b3, (float)(d3 * d3) + v);
     }
+    const float r[4] = {b0, b1, b2, b3};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (q0 + k < len) out[base + (size_t)(q0 + k) * stride] = takeSqrt ? sqrtf(r[k]) : r[k];
 }
 
 int launch_distance_transform_3d(float *in, float *out, int width, int height, int depth, int takeSqrt, hipStream_t st) {
@@ -200,9 +248,10 @@ int launch_distance_transform_3d(float *in, float *out, int width, int height, i
                            in, out, width, nLines, 0);
     }
     const int tilesX = (width + 63) / 64;
-    hipLaunchKernelGGL(dt_pass_strided_kernel, dim3(tilesX * height), dim3(256), sizeof(float) * 64 * (size_t)depth, st,
+    const int qcZ = (depth + DT_QCHUNK - 1) / DT_QCHUNK, qcY = (height + DT_QCHUNK - 1) / DT_QCHUNK;
+    hipLaunchKernelGGL(dt_pass_strided_kernel, dim3(tilesX * height * qcZ), dim3(256), sizeof(float) * 64 * (size_t)depth, st,
                        out, in, depth, width * height, width, height, width, 0);
-    hipLaunchKernelGGL(dt_pass_strided_kernel, dim3(tilesX * depth), dim3(256), sizeof(float) * 64 * (size_t)height, st,
+    hipLaunchKernelGGL(dt_pass_strided_kernel, dim3(tilesX * depth * qcY), dim3(256), sizeof(float) * 64 * (size_t)height, st,
                        in, out, height, width, width, depth, width * height, takeSqrt);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
@@ -374,7 +423,7 @@ int gn_launch_ne_mod2obs(const float *d_pred, int width, int height, const Model
 int gn_launch_raycast(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                       float *d_prediction, hipStream_t st) {
     const int tiles = ((width + 7) / 8) * ((height + 7) / 8);
-    hipLaunchKernelGGL(raycast_prediction_kernel, dim3((tiles + 3) / 4), dim3(256), sizeof(float) * 24 * (size_t)m.nSdfs, st,
+    hipLaunchKernelGGL(raycast_prediction_kernel, dim3(tiles), dim3(64 * RC_WAVES), 0, st,
                        flx, fly, ppx, ppy, width, height, modelNum, m, (float4 *)d_prediction, 0.0f);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
@@ -433,7 +482,7 @@ int dartk_raycast_prediction(float flx, float fly, float ppx, float ppy, int wid
     DARTK_REQUIRE(width > 0 && height > 0 && flx != 0 && fly != 0, "bad camera %dx%d f=(%g,%g)", width, height, flx, fly);
     DARTK_REQUIRE(modelNum >= 0 && modelNum < 32768, "modelNum %d out of range", modelNum);
     const int tiles = ((width + 7) / 8) * ((height + 7) / 8);
-    hipLaunchKernelGGL(raycast_prediction_kernel, dim3((tiles + 3) / 4), dim3(256), sizeof(float) * 24 * (size_t)mod->v.nSdfs,
+    hipLaunchKernelGGL(raycast_prediction_kernel, dim3(tiles), dim3(64 * RC_WAVES), 0,
                        as_stream(stream), flx, fly, ppx, ppy, width, height, modelNum, mod->v, (float4 *)d_prediction, levelSet);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;

@@ -82,15 +82,14 @@ int launch_reduce_slabs(const float *slabs, int nBlocks, int S, float *result, i
     return DARTK_OK;
 }
 
-__global__ void fk_kernel(ModelView m, int mode) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (mode == 0) {
-            float inv[12];
-            se3_invert(m.T_mc, inv);
-            for (int i = 0; i < 12; ++i) m.T_cm[i] = inv[i];
-        }
-        fk_device(m, mode);
+__global__ void __launch_bounds__(64) fk_kernel(ModelView m, int mode) {
+    __shared__ float sT[12 * (DARTK_MAX_JOINTS + 1)];
+    if (mode == 0 && threadIdx.x == 0) {
+        float inv[12];
+        se3_invert(m.T_mc, inv);
+        for (int i = 0; i < 12; ++i) m.T_cm[i] = inv[i];
     }
+    fk_wave(m, mode, sT);
 }
 
 }  // namespace dartk
