@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libdartk.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the association path must round exactly like the CPU restatement (no silent FMAs);
 # the accumulation loops ask for FMAs explicitly (__builtin_fmaf).
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+FLAGS = os.environ.get("DARTK_EXTRA_FLAGS", "").split() + ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(HERE, "..", "include")]
 
 

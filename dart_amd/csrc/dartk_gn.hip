@@ -39,12 +39,67 @@ struct ProfScope {
 // goes straight into an LDS row (the SDF gradient computed for the normal test is reused for the Jacobian) and
 // only the per-workgroup partial system and a count leave the CU.
 // -----------------------------------------------------------------------------------------------------
+// The observation is fixed for the whole optimizePose call, so the pixels that can ever associate (vertex w > 0)
+// are compacted once per call into an index list (deterministic: pixel order is kept), and every iteration's fused
+// kernel runs one full tile of real work per workgroup instead of striding over a mostly empty image.
+static constexpr int VC_BLOCK = 256;
+__global__ void __launch_bounds__(VC_BLOCK)
+valid_count_kernel(const float4 *__restrict__ vert, int nPix, int *__restrict__ blockCounts) {
+    __shared__ int wc[VC_BLOCK / 64];
+    const int index = blockIdx.x * VC_BLOCK + threadIdx.x;
+    const bool v = index < nPix && vert[index].w > 0;
+    const unsigned long long mask = __ballot(v);
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) blockCounts[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+// exclusive scan of the block counts in place (one workgroup, serial carry over chunks of 1024); total -> *nValid
+__global__ void __launch_bounds__(1024)
+valid_scan_kernel(int *__restrict__ blockCounts, int nBlocks, int *__restrict__ nValid) {
+    __shared__ int buf[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nBlocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nBlocks ? blockCounts[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int t = (int)threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int incl = buf[threadIdx.x];
+        const int c = carry;
+        if (i < nBlocks) blockCounts[i] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *nValid = carry;
+}
+__global__ void __launch_bounds__(VC_BLOCK)
+valid_write_kernel(const float4 *__restrict__ vert, int nPix, const int *__restrict__ blockOffsets, int *__restrict__ validIdx) {
+    __shared__ int wc[VC_BLOCK / 64];
+    const int index = blockIdx.x * VC_BLOCK + threadIdx.x;
+    const bool v = index < nPix && vert[index].w > 0;
+    int total;
+    const int slot = compact_slot<VC_BLOCK>(v, wc, total);
+    if (v) validIdx[blockOffsets[blockIdx.x] + slot] = index;
+}
+
+// One tile of NE_BLOCK valid pixels per workgroup; workgroups past the end of the list exit (their slab is never read).
 template <int PPT>
 __global__ void __launch_bounds__(NE_BLOCK)
-fused_obs2mod_kernel(const float4 *__restrict__ vert, const float4 *__restrict__ norm, int nPix, ModelView m,
+fused_obs2mod_kernel(const float4 *__restrict__ vert, const float4 *__restrict__ norm, const int *__restrict__ validIdx,
+                     const int *__restrict__ nValidPtr, ModelView m,
                      float distThr, float normThr, float planeOffset, float pnx, float pny, float pnz, float huberDelta,
                      float *__restrict__ slabs, int *__restrict__ count) {
     extern __shared__ float lds[];
+    const int nValid = *nValidPtr;
+    if ((int)blockIdx.x * NE_BLOCK >= nValid) return;
     const int d = 6 + m.nJoints;
     const int ld = row_len(d, false);
     float *sT_fm = lds;
@@ -58,64 +113,58 @@ fused_obs2mod_kernel(const float4 *__restrict__ vert, const float4 *__restrict__
 
     PairAcc<NE_BLOCK, PPT> acc;
     acc.init(d, false);
-    int myCount = 0;
-    const int nTiles = (nPix + NE_BLOCK - 1) / NE_BLOCK;
-    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
-        const int index = tile * NE_BLOCK + threadIdx.x;
-        bool active = false;
-        AssocResult r;
-        f3 gf; gf.x = gf.y = gf.z = 0.f;
-        int frame = 0;
-        if (index < nPix) {
-            const float4 xc = vert[index];
-            if (xc.w > 0) {
-                r = associate_point(m, xc, distThr, planeOffset, pnx, pny, pnz);
-                if (r.grid >= 0) {
-                    frame = m.sdfFrame[r.grid];
-                    const SdfDev &s = m.sdfs[r.grid];
-                    const f3 xf = se3_apply_w(sT_fm + 12 * frame, r.xm.x, r.xm.y, r.xm.z, r.w);
-                    const f3 xg = grid_coords(s, xf);
-                    gf = grid_gradient(m.grids + s.dataOff, s.dimx, s.dimy, xg);
-                    // normal test (obsToMod.cu:83-96), same arithmetic as normal_test()
-                    active = true;
-                    const float4 nObs = norm[index];
-                    if (nObs.w > 0.0f) {
-                        float T_fc[12], T_cf[12], T_f[12];
+    const int k = blockIdx.x * NE_BLOCK + threadIdx.x;
+    bool active = false;
+    AssocResult r;
+    f3 gf; gf.x = gf.y = gf.z = 0.f;
+    int frame = 0;
+    __syncthreads();        // staged transforms visible
+    if (k < nValid) {
+        const int index = validIdx[k];
+        const float4 xc = vert[index];
+        r = associate_point(m, xc, distThr, planeOffset, pnx, pny, pnz);
+        if (r.grid >= 0) {
+            frame = m.sdfFrame[r.grid];
+            const SdfDev &s = m.sdfs[r.grid];
+            const f3 xf = se3_apply_w(sT_fm + 12 * frame, r.xm.x, r.xm.y, r.xm.z, r.w);
+            const f3 xg = grid_coords(s, xf);
+            gf = grid_gradient(m.grids + s.dataOff, s.dimx, s.dimy, xg);
+            // normal test (obsToMod.cu:83-96), same arithmetic as normal_test()
+            active = true;
+            const float4 nObs = norm[index];
+            if (nObs.w > 0.0f) {
+                float T_fc[12], T_cf[12], T_f[12];
 #pragma unroll
-                        for (int i = 0; i < 12; ++i) T_f[i] = sT_fm[12 * frame + i];
-                        se3_mul(T_f, T_mc, T_fc);
-                        se3_invert(T_fc, T_cf);
-                        const float invLen = 1.0f / sqrtf(gf.x * gf.x + gf.y * gf.y + gf.z * gf.z + 0.0f * 0.0f);
-                        const float gw = 0.0f * invLen;
-                        const f3 n = se3_apply_w(T_cf, gf.x * invLen, gf.y * invLen, gf.z * invLen, gw);
-                        const float dp = (-1 * n.x) * nObs.x + (-1 * n.y) * nObs.y + (-1 * n.z) * nObs.z + (-1 * gw) * 0.0f;
-                        if (dp < normThr) active = false;
-                    }
-                }
+                for (int i = 0; i < 12; ++i) T_f[i] = sT_fm[12 * frame + i];
+                se3_mul(T_f, T_mc, T_fc);
+                se3_invert(T_fc, T_cf);
+                const float invLen = 1.0f / sqrtf(gf.x * gf.x + gf.y * gf.y + gf.z * gf.z + 0.0f * 0.0f);
+                const float gw = 0.0f * invLen;
+                const f3 n = se3_apply_w(T_cf, gf.x * invLen, gf.y * invLen, gf.z * invLen, gw);
+                const float dp = (-1 * n.x) * nObs.x + (-1 * n.y) * nObs.y + (-1 * n.z) * nObs.z + (-1 * gw) * 0.0f;
+                if (dp < normThr) active = false;
             }
         }
-        int nActive;
-        const int slot = compact_slot<NE_BLOCK>(active, waveCnt, nActive);
-        if (active) {
-            float *row = rows + slot * ld;
-            const f3 gm = se3_rotate(sT_mf + 12 * frame, gf);
-            error_jacobian<false>(row, r.xm, r.w, m.depMask[frame], gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
-            const float err = r.err;
-            float rr, E;
-            if (fabsf(err) < huberDelta) { rr = -err; E = (float)(0.5 * (double)rr * (double)rr); }
-            else {
-                rr = (err < 0) ? huberDelta : -huberDelta;
-                E = (float)((double)huberDelta * ((double)fabsf(err) - 0.5 * (double)huberDelta));
-            }
-            row[d] = rr; row[d + 1] = E; row[d + 2] = 1.0f;
-        }
-        __syncthreads();
-        if (nActive) acc.accumulate(rows, ld, nActive);
-        myCount += nActive;
-        __syncthreads();
     }
+    int nActive;
+    const int slot = compact_slot<NE_BLOCK>(active, waveCnt, nActive);
+    if (active) {
+        float *row = rows + slot * ld;
+        const f3 gm = se3_rotate(sT_mf + 12 * frame, gf);
+        error_jacobian<false>(row, r.xm, r.w, m.depMask[frame], gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
+        const float err = r.err;
+        float rr, E;
+        if (fabsf(err) < huberDelta) { rr = -err; E = (float)(0.5 * (double)rr * (double)rr); }
+        else {
+            rr = (err < 0) ? huberDelta : -huberDelta;
+            E = (float)((double)huberDelta * ((double)fabsf(err) - 0.5 * (double)huberDelta));
+        }
+        row[d] = rr; row[d + 1] = E; row[d + 2] = 1.0f;
+    }
+    __syncthreads();
+    if (nActive) acc.accumulate(rows, ld, nActive);
     acc.store(slabs + (size_t)blockIdx.x * sys_size(d), sys_size(d));
-    if (threadIdx.x == 0 && myCount) atomicAdd(count, myCount);
+    if (threadIdx.x == 0 && nActive) atomicAdd(count, nActive);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -125,6 +174,7 @@ fused_obs2mod_kernel(const float4 *__restrict__ vert, const float4 *__restrict__
 struct ReduceTerm {
     const float *slabs; int nBlocks; int S;
     const int *count; int minCount;      // system kept only if *count > minCount (obsToMod.cu:646); count may be null
+    const int *nItems; int itemsPerBlock; // when set: only the first ceil(*nItems / itemsPerBlock) slabs were written
     float *out;
 };
 struct ReduceArgs { ReduceTerm t[4]; };
@@ -140,10 +190,11 @@ gn_reduce_kernel(ReduceArgs a) {
     const int q = threadIdx.x >> 6;
     if (blockIdx.x * 64 >= t.S) return;
     const bool keep = t.slabs && (!t.count || *t.count > t.minCount);
+    const int nBlocks = t.nItems ? min(t.nBlocks, (*t.nItems + t.itemsPerBlock - 1) / t.itemsPerBlock) : t.nBlocks;
     double s = 0.0;
     if (keep && o < t.S) {
-        const int per = (t.nBlocks + 3) >> 2;
-        const int b0 = q * per, b1 = min(t.nBlocks, b0 + per);
+        const int per = (nBlocks + 3) >> 2;
+        const int b0 = q * per, b1 = min(nBlocks, b0 + per);
         const float *p = t.slabs + (size_t)b0 * t.S + o;
         int b = b0;
         for (; b + 8 <= b1; b += 8) {
@@ -201,18 +252,21 @@ __device__ void ldlt_solve_wave(float *A, int ld, int n, const float *b, float *
         }
         const float dk = A[k * ld + k];
         if (dk == 0.0f) continue;          // wave-uniform
-        for (int i = k + 1 + lane; i < n; i += 64) A[i * ld + k] /= dk;
+        for (int i = k + 1 + lane; i < n; i += 64) { const float l = A[i * ld + k] / dk; A[i * ld + k] = l; y[i] = l; }
         wave_sync();
-        // trailing update on the lower triangle, mirrored (8x8 lane tile over (i,j))
-        const int m = n - k - 1;
-        const int li = lane >> 3, lj = lane & 7;
-        for (int bi = 0; bi < m; bi += 8) {
-            for (int bj = 0; bj <= bi; bj += 8) {
-                const int i = k + 1 + bi + li, j = k + 1 + bj + lj;
-                if (i < n && j <= i) {
-                    const float v = A[i * ld + j] - A[i * ld + k] * dk * A[j * ld + k];
-                    A[i * ld + j] = v;
-                    A[j * ld + i] = v;
+        // trailing update: lane j owns COLUMN j and walks the rows; L[.][k] is read from its copy in y (broadcast reads
+        // that do not alias the column being written, so the loads pipeline). The oracle updates the lower triangle as
+        // A[i][j] -= (L[i][k]*dk)*L[j][k] (i >= j) and mirrors it, so the upper entries take the mirrored product order.
+        {
+            const float *__restrict__ Lk = y;
+            for (int j = k + 1 + lane; j < n; j += 64) {
+                const float lj = Lk[j];
+                float *__restrict__ col = A + j;
+#pragma unroll 4
+                for (int i = k + 1; i < n; ++i) {
+                    const float li = Lk[i];
+                    const float prod = (i >= j) ? (li * dk) * lj : (lj * dk) * li;
+                    col[i * ld] = col[i * ld] - prod;
                 }
             }
         }
@@ -239,6 +293,82 @@ __device__ void ldlt_solve_wave(float *A, int ld, int n, const float *b, float *
     wave_sync();
 }
 
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// wave-wide maximum of a 32-bit key by DPP (gfx9 row operations), result uniform
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast15 -> rows 1,3
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast31 -> rows 2,3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// LDL^T with diagonal pivoting + solve for n <= 64 by ONE wave, lane j = unknown j. The symmetric matrix stays in LDS
+// (row stride ld, odd) and is never permuted: step k picks the not-yet-eliminated index p with the largest |diagonal|
+// (the pivot Eigen's ldlt() / the oracle pick, ties to the lowest index), scales row p into L and applies the rank-1
+// update to the remaining columns, lane j walking column j. Per step: one DPP arg-max, one division per lane, and
+// 2 LDS reads + 1 write per remaining row. The substitutions run in pivot order on a per-lane register. x[j] = lane j.
+__device__ void ldlt_solve_wave64(float *A, int ld, int n, const float *b, float *x, int *order, float *Lk) {
+    const int lane = threadIdx.x & 63;
+    const bool mine = lane < n;
+    float dj = mine ? A[lane * ld + lane] : 0.0f;     // running diagonal of this lane's index
+    float dpiv = 0.0f;                                // pivot value once this index has been eliminated
+    unsigned long long todo = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    for (int k = 0; k < n; ++k) {
+        const bool open = mine && ((todo >> lane) & 1ull);
+        const unsigned key = open ? (__float_as_uint(fabsf(dj)) + 1u) : 0u;
+        const unsigned best = wave_max_u32(key);
+        const int p = __builtin_ctzll(__ballot(key == best));
+        const float dk = readlane_f(dj, p);
+        if (lane == 0) order[k] = p;
+        if (lane == p) dpiv = dk;
+        todo &= ~(1ull << p);
+        if (dk == 0.0f) continue;          // wave-uniform; the oracle / Eigen leave the column untouched
+        const bool rest = mine && ((todo >> lane) & 1ull);
+        float lj = 0.0f;
+        if (rest) {
+            lj = A[p * ld + lane] / dk;
+            A[p * ld + lane] = lj;         // row p is dead from here on: it keeps L[.][p]
+            Lk[lane] = lj;
+            dj = dj - (lj * dk) * lj;
+        }
+        wave_sync();
+        if (rest) {
+            float *__restrict__ col = A + lane;
+            const float *__restrict__ L = Lk;
+            for (unsigned long long msk = todo; msk; msk &= msk - 1ull) {
+                const int i = __builtin_ctzll(msk);
+                col[i * ld] = col[i * ld] - (L[i] * dk) * lj;
+            }
+        }
+        wave_sync();
+    }
+    // forward substitution in pivot order: y_k = b[p_k] - sum_{m<k} L[p_k][p_m] y_m
+    float yv = mine ? b[lane] : 0.0f;
+    todo = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    for (int k = 0; k < n; ++k) {
+        const int p = __builtin_amdgcn_readfirstlane(order[k]);
+        const float yp = readlane_f(yv, p);
+        todo &= ~(1ull << p);
+        if (mine && ((todo >> lane) & 1ull)) yv -= A[p * ld + lane] * yp;
+    }
+    // D^-1 (Eigen's pseudo-inverse: tiny pivots give 0)
+    yv = (fabsf(dpiv) > 1.17549435e-38f) ? yv / dpiv : 0.0f;
+    // backward substitution with L^T: x_{p_k} = y_k - sum_{m>k} L[p_m][p_k] x_{p_m}
+    unsigned long long doneMask = 0ull;
+    for (int k = n - 1; k >= 0; --k) {
+        const int p = __builtin_amdgcn_readfirstlane(order[k]);
+        const float xp = readlane_f(yv, p);
+        doneMask |= (1ull << p);
+        if (mine && !((doneMask >> lane) & 1ull)) yv -= A[lane * ld + p] * xp;
+    }
+    if (mine) x[lane] = yv;
+    wave_sync();
+}
+
 // assemble + solve + update + forward kinematics (optimizer.cpp:482-518), ONE wave.
 __global__ void __launch_bounds__(64)
 gn_solve_single_kernel(ModelView m, SolveArgs a) {
@@ -246,7 +376,7 @@ gn_solve_single_kernel(ModelView m, SolveArgs a) {
     const int d = 6 + m.nJoints;
     const int ad = d - 6;
     const int S = sys_size(d), Sa = sys_size(ad);
-    const int ld = d + 1;
+    const int ld = (d + 1) | 1;             // odd row stride: row and column walks are both bank-conflict free
     float *JTJ = lds;                       // [d][ld]
     float *eJ = JTJ + d * ld;
     float *x = eJ + d;
@@ -255,6 +385,9 @@ gn_solve_single_kernel(ModelView m, SolveArgs a) {
     float *sT = reinterpret_cast<float *>(perm + d);      // forward-kinematics scratch, 12*nFrames
     const int tid = threadIdx.x;
     const float *__restrict__ sysA = a.sysA, *__restrict__ sysB = a.sysB, *__restrict__ sysC = a.sysC;
+#ifdef DARTK_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     if (a.firstSystem) {
         for (int o = tid; o < S; o += 64) { a.firstSystem[o] = sysA ? sysA[o] : 0.0f; a.firstSystem[S + o] = sysB ? sysB[o] : 0.0f; }
@@ -295,7 +428,14 @@ gn_solve_single_kernel(ModelView m, SolveArgs a) {
         *a.countA = 0; *a.countB = 0;       // ready for the next iteration's kernels (stream order)
     }
     wave_sync();
-    ldlt_solve_wave(JTJ, ld, d, eJ, x, perm, y);
+#ifdef DARTK_STAMPS
+    const unsigned long long st1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (d <= 64) ldlt_solve_wave64(JTJ, ld, d, eJ, x, perm, y);
+    else ldlt_solve_wave(JTJ, ld, d, eJ, x, perm, y);
+#ifdef DARTK_STAMPS
+    const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (tid == 0) {
         float t6[6], dT[12], T[12], Tn[12], Tinv[12];
         for (int i = 0; i < 6; ++i) t6[i] = -x[i];
@@ -311,10 +451,17 @@ gn_solve_single_kernel(ModelView m, SolveArgs a) {
     }
     // forward kinematics for the next iteration (MirroredModel::setPose); lane j re-reads the joint it just wrote
     fk_wave(m, 0, sT);
+#ifdef DARTK_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && a.iterInfo) {   // diagnostic build only: 10 ns ticks of assemble / LDL^T / update+FK in the spare slots
+        a.iterInfo[5] = (float)(st1 - st0); a.iterInfo[6] = (float)(st2 - st1); a.iterInfo[7] = (float)(st3 - st2);
+    }
+#endif
 }
 
 static size_t solve_lds_bytes(int d, int nFrames) {
-    return sizeof(float) * (size_t)(d * (d + 1) + 4 * d + 12 * nFrames + 8);
+    return sizeof(float) * (size_t)(d * (d + 2) + 4 * d + 12 * nFrames + 8);
 }
 
 }  // namespace dartk
@@ -368,29 +515,43 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     Workspace *ws;
     int rc = get_workspace(&ws);
     if (rc) return rc;
-    rc = ensure_partials(ws, (size_t)3 * GN_MAX_BLOCKS * S);
+    const int nPix = width * height;
+    const int tilesA = (nPix + NE_BLOCK - 1) / NE_BLOCK;
+    const int nBlocksA = tilesA;                 // one tile of compacted valid pixels per workgroup (worst case: all valid)
+    rc = ensure_partials(ws, (size_t)(2 * GN_MAX_BLOCKS + nBlocksA) * S);
     if (rc) return rc;
-    float *slabsA = ws->partials, *slabsB = slabsA + (size_t)GN_MAX_BLOCKS * S, *slabsC = slabsB + (size_t)GN_MAX_BLOCKS * S;
-    int *cntA = ws->counters, *cntB = ws->counters + 1;
+    float *slabsB = ws->partials, *slabsC = slabsB + (size_t)GN_MAX_BLOCKS * S, *slabsA = slabsC + (size_t)GN_MAX_BLOCKS * S;
+    int *cntA = ws->counters, *cntB = ws->counters + 1, *d_nValid = ws->counters + 2;
+    const int nVcBlocks = (nPix + VC_BLOCK - 1) / VC_BLOCK;
+    rc = ensure_valid_idx(ws, (size_t)nPix + nVcBlocks);
+    if (rc) return rc;
+    int *validIdx = ws->validIdx, *vcOffsets = ws->validIdx + nPix;
     float *d_T_gc = ws->sysScratch + 128;      // camera -> obs-SDF frame, frozen at the start (optimizer.cpp:446-448)
     float *sysA = ws->sysScratch + kMaxSys, *sysB = sysA + kMaxSys, *sysC = sysB + kMaxSys;   // reduced packed systems
 
-    const int nPix = width * height;
-    const int tilesA = (nPix + NE_BLOCK - 1) / NE_BLOCK;
-    const int nBlocksA = tilesA < GN_MAX_BLOCKS ? tilesA : GN_MAX_BLOCKS;
     const int nPred = o->predWidth * o->predHeight;
     const int tilesB = (nPred + NE_BLOCK - 1) / NE_BLOCK;
     const int nBlocksB = tilesB < GN_MAX_BLOCKS ? tilesB : GN_MAX_BLOCKS;
     const int tilesC = (nCloud + NE_BLOCK - 1) / NE_BLOCK;
     const int nBlocksC = tilesC < GN_MAX_BLOCKS ? tilesC : GN_MAX_BLOCKS;
 
+    // The mod->obs chain (obs-SDF build, ray-cast, normal equations) and the obs->mod chain (valid-pixel compaction,
+    // fused association + normal equations) only meet in the solve: with both terms on they run on two streams,
+    // forked after the pose is final and joined before the reduction (the reference overlaps its ray-cast and its
+    // association the same way, optimizer.cpp:610-639). Each chain alone leaves most of the chip idle.
+    const bool fork = useA && useB && o->numIterations > 0;
+    hipStream_t stB = fork ? ws->auxStream : st;
+    if (fork) {
+        DARTK_HIP(hipEventRecord(ws->evFork, st));
+        DARTK_HIP(hipStreamWaitEvent(stB, ws->evFork, 0));
+    }
     if (useB) {
         {
-            ProfScope ps(DARTK_PROF_OBS_SDF, st);
-            rc = gn_obs_sdf_build(d_vert, width, height, mod, o->focalLength, st);
+            ProfScope ps(DARTK_PROF_OBS_SDF, stB);
+            rc = gn_obs_sdf_build(d_vert, width, height, mod, o->focalLength, stB);
         }
         if (rc) return rc;
-        DARTK_HIP(hipMemcpyAsync(d_T_gc, m.T_mc, 12 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        DARTK_HIP(hipMemcpyAsync(d_T_gc, m.T_mc, 12 * sizeof(float), hipMemcpyDeviceToDevice, stB));
     }
     const size_t ldsA = sizeof(float) * (24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8);
     const size_t ldsS = solve_lds_bytes(d, m.nFrames);
@@ -399,12 +560,31 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         DARTK_HIP(hipFuncSetAttribute((const void *)gn_solve_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS));
 
     DARTK_HIP(hipMemsetAsync(ws->counters, 0, 2 * sizeof(int), st));      // later iterations: zeroed by the solve kernel
+    if (useA && o->numIterations > 0) {
+        ProfScope ps(DARTK_PROF_OTHER, st);
+        hipLaunchKernelGGL(valid_count_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, st, (const float4 *)d_vert, nPix, vcOffsets);
+        hipLaunchKernelGGL(valid_scan_kernel, dim3(1), dim3(1024), 0, st, vcOffsets, nVcBlocks, d_nValid);
+        hipLaunchKernelGGL(valid_write_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, st, (const float4 *)d_vert, nPix, vcOffsets, validIdx);
+        DARTK_HIP(hipGetLastError());
+    }
     for (int it = 0; it < o->numIterations; ++it) {
+        if (fork && it > 0) {       // the pose of this iteration is final on `st` (previous solve)
+            DARTK_HIP(hipEventRecord(ws->evFork, st));
+            DARTK_HIP(hipStreamWaitEvent(stB, ws->evFork, 0));
+        }
         if (useB) {
-            ProfScope ps(DARTK_PROF_RAYCAST, st);
-            rc = gn_launch_raycast(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2),
-                                   o->predWidth, o->predHeight, 0, m, d_prediction, st);
-            if (rc) return rc;
+            {
+                ProfScope ps(DARTK_PROF_RAYCAST, stB);
+                rc = gn_launch_raycast(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2),
+                                       o->predWidth, o->predHeight, 0, m, d_prediction, stB);
+                if (rc) return rc;
+            }
+            {
+                ProfScope ps(DARTK_PROF_NE_MOD2OBS, stB);
+                rc = gn_launch_ne_mod2obs(d_prediction, o->predWidth, o->predHeight, m, d_T_gc, slabsB, nBlocksB, cntB, stB);
+                if (rc) return rc;
+            }
+            if (fork) DARTK_HIP(hipEventRecord(ws->evJoin, stB));
         }
         if (useA) {
             ProfScope ps(DARTK_PROF_FUSED_OBS2MOD, st);
@@ -414,7 +594,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         if (ldsA > 64 * 1024)                                                                                   \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA)); \
         hipLaunchKernelGGL(kfn, dim3(nBlocksA), dim3(NE_BLOCK), ldsA, st, (const float4 *)d_vert, (const float4 *)d_norm, \
-                           nPix, m, o->distThreshold, o->normThreshold, o->planeOffset, o->planeNormal[0],      \
+                           validIdx, d_nValid, m, o->distThreshold, o->normThreshold, o->planeOffset, o->planeNormal[0],      \
                            o->planeNormal[1], o->planeNormal[2], o->huberDelta, slabsA, cntA);                  \
     } while (0)
             if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_FUSED(3);
@@ -423,22 +603,18 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
 #undef DARTK_LAUNCH_FUSED
             DARTK_HIP(hipGetLastError());
         }
-        if (useB) {
-            ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
-            rc = gn_launch_ne_mod2obs(d_prediction, o->predWidth, o->predHeight, m, d_T_gc, slabsB, nBlocksB, cntB, st);
-            if (rc) return rc;
-        }
         if (useC) {
             ProfScope ps(DARTK_PROF_NE_SELF, st);
             rc = gn_launch_ne_self(d_cloud, nCloud, m, d_potential, slabsC, nBlocksC, st);
             if (rc) return rc;
         }
+        if (fork) DARTK_HIP(hipStreamWaitEvent(st, ws->evJoin, 0));
         const int Sa = sys_size(d - 6);
         ReduceArgs ra = {};
         int nTerms = 0;
-        if (useA) ra.t[nTerms++] = ReduceTerm{slabsA, nBlocksA, S, cntA, 10, sysA};
-        if (useB) ra.t[nTerms++] = ReduceTerm{slabsB, nBlocksB, S, nullptr, 0, sysB};
-        if (useC) ra.t[nTerms++] = ReduceTerm{slabsC, nBlocksC, Sa, nullptr, 0, sysC};
+        if (useA) ra.t[nTerms++] = ReduceTerm{slabsA, nBlocksA, S, cntA, 10, d_nValid, NE_BLOCK, sysA};
+        if (useB) ra.t[nTerms++] = ReduceTerm{slabsB, nBlocksB, S, nullptr, 0, nullptr, 0, sysB};
+        if (useC) ra.t[nTerms++] = ReduceTerm{slabsC, nBlocksC, Sa, nullptr, 0, nullptr, 0, sysC};
         SolveArgs a;
         a.sysA = useA ? sysA : nullptr; a.countA = cntA;
         a.sysB = useB ? sysB : nullptr; a.countB = cntB;

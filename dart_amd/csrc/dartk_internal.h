@@ -79,6 +79,12 @@ struct Workspace {
     size_t partialFloats;
     int *counters;         // small int scratch
     float *sysScratch;     // packed systems (device GN loop)
+    float *rayBuf;         // ray-cast traces: [nSdfs][nPix] {detection t, hit t}
+    size_t rayFloats;
+    int *validIdx;         // compacted indices of valid observation pixels + block offsets
+    size_t validInts;
+    hipStream_t auxStream; // second stream: the mod->obs chain runs beside the obs->mod chain (fork/join by events)
+    hipEvent_t evFork, evJoin;
 };
 int get_workspace(Workspace **ws);
 static constexpr int kMaxPartialBlocks = 2048;

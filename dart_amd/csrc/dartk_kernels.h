@@ -11,6 +11,8 @@ static constexpr int NE_BLOCK = 128;   // lanes (= points per tile) of every nor
 
 int ensure_partials(Workspace *w, size_t floats);
 int get_multi_args_buffer(void **d_ptr, size_t bytes);
+int ensure_ray_buf(Workspace *w, size_t floats);
+int ensure_valid_idx(Workspace *w, size_t ints);
 
 // kernel-only launchers used by the device-resident Gauss-Newton loops (dartk_gn.hip)
 int gn_launch_raycast(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,

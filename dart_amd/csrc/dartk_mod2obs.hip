@@ -9,34 +9,19 @@
 namespace dartk {
 
 // -----------------------------------------------------------------------------------------------------
-// ray-cast prediction (raycast.cu:121-215). The reference walks one ray per thread through every SDF in turn,
-// a serial chain of ~nSdfs sphere-traces whose only coupling is the running closest hit. Here a workgroup owns an
-// 8x8 pixel tile and its 4 waves trace 4 SDFs at a time for the same 64 rays (lane = ray, wave = SDF): each
-// (ray, SDF) trace records the step position at which its first zero crossing was DETECTED and the refined hit;
-// wave 0 then replays the reference's sequential rule in SDF order -- a crossing counts iff its detection step
-// lies before the closest hit so far (the reference's `t0 < closestT` loop test) -- so the map is identical to
-// the serial walk. Traces of later rounds are cut at the closest hit of the earlier rounds (the reference's
-// pruning, one round coarser). Per-SDF camera<->frame transforms are composed once per workgroup into LDS.
+// ray-cast prediction (raycast.cu:121-215). The reference walks one ray per thread through every SDF in turn: a
+// serial chain of ~nSdfs sphere-traces (each step a dependent 8-voxel gather) whose only coupling is the running
+// closest hit. Here the (ray, SDF) traces are independent work items: wave = one 8x8 pixel tile against one SDF
+// (tiles x nSdfs waves fill the chip; neighbouring rays march together through the same voxels). Each trace
+// records the step position at which its first zero crossing was DETECTED and the refined hit; a second,
+// per-pixel kernel replays the reference's sequential rule in SDF order -- a crossing counts iff its detection
+// step lies before the closest hit so far (the reference's `t0 < closestT` loop test) -- so the map is
+// identical to the serial walk; what is given up is the reference's pruning of traces behind the closest hit.
 // -----------------------------------------------------------------------------------------------------
-static constexpr int RC_WAVES = 4;
-__global__ void __launch_bounds__(64 * RC_WAVES)
-raycast_prediction_kernel(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, ModelView m,
-                          float4 *__restrict__ prediction, float levelSet) {
-    __shared__ float sT[RC_WAVES * 24];        // per SDF of the round: T_fc then T_cf
-    __shared__ float sDet[RC_WAVES * 64];
-    __shared__ float sHit[RC_WAVES * 64];
-    __shared__ float sClosest[64];
-    const int tilesX = (width + 7) >> 3;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = (blockIdx.x % tilesX) * 8 + (lane & 7);
-    const int y = (blockIdx.x / tilesX) * 8 + (lane >> 3);
-    const bool valid = x < width && y < height;
-    const int index = x + y * width;
-    float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (wave == 0 && valid) {
-        pr = prediction[index];
-        if (modelNum == 0) { pr.z = 0; pr.w = -1; }
-    }
+struct RayGeom { f3 of, dn; };
+
+// ray of pixel (x,y) expressed in the frame of an SDF whose camera->frame transform is T_fc (raycast.cu:147-161)
+__device__ __forceinline__ RayGeom ray_in_frame(const float *T_fc, int x, int y, float flx, float fly, float ppx, float ppy) {
     const float invflx = 1.0f / flx, invfly = 1.0f / fly;
     const float uvx = (float)((double)x + 0.5), uvy = (float)((double)y + 0.5);
     f3 rd; rd.x = (uvx - ppx) * invflx; rd.y = (uvy - ppy) * invfly; rd.z = 1.0f;
@@ -44,98 +29,139 @@ raycast_prediction_kernel(float flx, float fly, float ppx, float ppy, int width,
         const float inv = 1.0f / sqrtf(rd.x * rd.x + rd.y * rd.y + rd.z * rd.z);
         rd.x *= inv; rd.y *= inv; rd.z *= inv;
     }
+    RayGeom g;
+    g.of = se3_apply_w(T_fc, 0.f, 0.f, 0.f, 1.f);
+    const f3 df = se3_apply_w(T_fc, rd.x, rd.y, rd.z, 0.f);
+    const float inv = 1.0f / sqrtf(df.x * df.x + df.y * df.y + df.z * df.z);
+    g.dn.x = df.x * inv; g.dn.y = df.y * inv; g.dn.z = df.z * inv;
+    return g;
+}
+
+__global__ void __launch_bounds__(256)
+raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int height, ModelView m,
+                     float2 *__restrict__ trace /*[nSdfs][width*height]*/, float levelSet) {
+    const int tilesX = (width + 7) >> 3, tilesY = (height + 7) >> 3;
+    const int nTiles = tilesX * tilesY;
+    const int lane = threadIdx.x & 63;
+    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // tile fastest, SDF slowest
+    if (task >= nTiles * m.nSdfs) return;
+    const int s = task / nTiles, tile = task - s * nTiles;
+    const int x = (tile % tilesX) * 8 + (lane & 7);
+    const int y = (tile / tilesX) * 8 + (lane >> 3);
+    if (x >= width || y >= height) return;
+    float T_fc[12];
+    {
+        const int f = m.sdfFrame[s];
+        float T_fm[12], T_mc[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { T_fm[i] = m.T_fm[12 * f + i]; T_mc[i] = m.T_mc[i]; }
+        se3_mul(T_fm, T_mc, T_fc);              // T_fms[f]*T_mc
+    }
+    const RayGeom g = ray_in_frame(T_fc, x, y, flx, fly, ppx, ppy);
+    const f3 of = g.of, dn = g.dn;
+    const SdfDev &sdf = m.sdfs[s];
+    const float smaxx = sdf.ox + sdf.res * (float)(unsigned)sdf.dimx;
+    const float smaxy = sdf.oy + sdf.res * (float)(unsigned)sdf.dimy;
+    const float smaxz = sdf.oz + sdf.res * (float)(unsigned)sdf.dimz;
+    const float hix = (float)((unsigned)sdf.dimx - 2u), hiy = (float)((unsigned)sdf.dimy - 2u), hiz = (float)((unsigned)sdf.dimz - 2u);
+    float t0, t1;   // intersectBox, raycast.cu:11-35
+    {
+        const float ix = 1.0f / dn.x, iy = 1.0f / dn.y, iz = 1.0f / dn.z;
+        const float bx = ix * (sdf.ox - of.x), by = iy * (sdf.oy - of.y), bz = iz * (sdf.oz - of.z);
+        const float tx = ix * (smaxx - of.x), ty = iy * (smaxy - of.y), tz = iz * (smaxz - of.z);
+        t0 = fmaxf(fmaxf(fminf(tx, bx), fminf(ty, by)), fminf(tz, bz));
+        t1 = fminf(fminf(fmaxf(tx, bx), fmaxf(ty, by)), fmaxf(tz, bz));
+    }
+    float det = 3.0e38f, hit = 0.0f;
+    if (t1 > t0) {
+        const float *data = m.grids + sdf.dataOff;
+        auto eval = [&](float tt) -> float {
+            f3 xf, xg;
+            xf.x = dn.x * tt + of.x; xf.y = dn.y * tt + of.y; xf.z = dn.z * tt + of.z;
+            xg.x = fmaxf(1.0f, fminf((xf.x - sdf.ox) / sdf.res, hix));
+            xg.y = fmaxf(1.0f, fminf((xf.y - sdf.oy) / sdf.res, hiy));
+            xg.z = fmaxf(1.0f, fminf((xf.z - sdf.oz) / sdf.res, hiz));
+            return grid_value(data, sdf.dimx, sdf.dimy, xg) * sdf.res;
+        };
+        float sdfValPrev = eval(t0);
+        float tPrev = t0;
+        const float minStep = sdf.res / 10;
+        while (t0 < t1 && t0 < 10000.0f) {      // 10000 = the reference's initial closestT
+            const float sdfVal = eval(t0);
+            if (sdfValPrev > levelSet && sdfVal <= levelSet) {
+                det = t0;
+                hit = (t0 - tPrev) * (levelSet - sdfValPrev) / (sdfVal - sdfValPrev) + tPrev;
+                break;      // the reference's loop ends here too: closestT = hit <= t0 < the next t0
+            }
+            sdfValPrev = sdfVal;
+            tPrev = t0;
+            t0 += fmaxf(minStep, fabsf(sdfVal));
+        }
+    }
+    trace[(size_t)s * width * height + (x + y * width)] = make_float2(det, hit);
+}
+
+static constexpr int RC_REPLAY_SDFS = 64;    // per-SDF transforms staged in LDS, this many at a time
+__global__ void __launch_bounds__(256)
+raycast_replay_kernel(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, ModelView m,
+                      const float2 *__restrict__ trace, float4 *__restrict__ prediction) {
+    __shared__ float sT[RC_REPLAY_SDFS * 24];   // T_fc then T_cf per SDF
+    const int nPix = width * height;
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = index < nPix;
+    const int x = valid ? index % width : 0, y = valid ? index / width : 0;
+    float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+        pr = prediction[index];
+        if (modelNum == 0) { pr.z = 0; pr.w = -1; }
+    }
     float closestT = 10000;
-    if (wave == 0) sClosest[lane] = closestT;
-    const int nSdfs = m.nSdfs;
-    for (int s0 = 0; s0 < nSdfs; s0 += RC_WAVES) {
-        const int nc = min(RC_WAVES, nSdfs - s0);
-        __syncthreads();                        // previous round's replay is finished with sT / sDet / sHit
-        if (threadIdx.x < nc) {
+    for (int s0 = 0; s0 < m.nSdfs; s0 += RC_REPLAY_SDFS) {
+        const int nc = min(RC_REPLAY_SDFS, m.nSdfs - s0);
+        __syncthreads();
+        if ((int)threadIdx.x < nc) {
             const int f = m.sdfFrame[s0 + threadIdx.x];
             float T_fm[12], T_mf[12], T_mc[12], T_cm[12], T_fc[12], T_cf[12];
             for (int i = 0; i < 12; ++i) { T_fm[i] = m.T_fm[12 * f + i]; T_mf[i] = m.T_mf[12 * f + i]; T_mc[i] = m.T_mc[i]; }
             se3_invert(T_mc, T_cm);                 // raycast.cu:143
-            se3_mul(T_fm, T_mc, T_fc);              // T_fms[f]*T_mc
+            se3_mul(T_fm, T_mc, T_fc);
             se3_mul(T_cm, T_mf, T_cf);              // T_cm*T_mfs[f]
             for (int i = 0; i < 12; ++i) { sT[24 * threadIdx.x + i] = T_fc[i]; sT[24 * threadIdx.x + 12 + i] = T_cf[i]; }
         }
         __syncthreads();
-        if (wave < nc) {
-            float det = 3.0e38f, hit = 0.0f;
-            if (valid) {
-                const float limitT = sClosest[lane];
-                const SdfDev &sdf = m.sdfs[s0 + wave];
-                const float *T_fc = sT + 24 * wave;
-                const f3 of = se3_apply_w(T_fc, 0.f, 0.f, 0.f, 1.f);
-                const f3 df = se3_apply_w(T_fc, rd.x, rd.y, rd.z, 0.f);
-                f3 dn;
-                {
-                    const float inv = 1.0f / sqrtf(df.x * df.x + df.y * df.y + df.z * df.z);
-                    dn.x = df.x * inv; dn.y = df.y * inv; dn.z = df.z * inv;
+        if (!valid) continue;
+        for (int k = 0; k < nc; ++k) {
+            const float2 dh = trace[(size_t)(s0 + k) * nPix + index];
+            if (dh.x < closestT) {
+                const float tHit = dh.y;
+                const RayGeom g = ray_in_frame(sT + 24 * k, x, y, flx, fly, ppx, ppy);
+                const f3 xc = se3_apply_w(sT + 24 * k + 12, g.dn.x * tHit + g.of.x, g.dn.y * tHit + g.of.y, g.dn.z * tHit + g.of.z, 1.0f);
+                if (pr.z == 0 || xc.z < pr.z) {
+                    pr.x = xc.x; pr.y = xc.y; pr.z = xc.z; pr.w = (float)((modelNum << 16) + s0 + k);
                 }
-                const float smaxx = sdf.ox + sdf.res * (float)(unsigned)sdf.dimx;
-                const float smaxy = sdf.oy + sdf.res * (float)(unsigned)sdf.dimy;
-                const float smaxz = sdf.oz + sdf.res * (float)(unsigned)sdf.dimz;
-                const float hix = (float)((unsigned)sdf.dimx - 2u), hiy = (float)((unsigned)sdf.dimy - 2u), hiz = (float)((unsigned)sdf.dimz - 2u);
-                float t0, t1;   // intersectBox, raycast.cu:11-35
-                {
-                    const float ix = 1.0f / dn.x, iy = 1.0f / dn.y, iz = 1.0f / dn.z;
-                    const float bx = ix * (sdf.ox - of.x), by = iy * (sdf.oy - of.y), bz = iz * (sdf.oz - of.z);
-                    const float tx = ix * (smaxx - of.x), ty = iy * (smaxy - of.y), tz = iz * (smaxz - of.z);
-                    t0 = fmaxf(fmaxf(fminf(tx, bx), fminf(ty, by)), fminf(tz, bz));
-                    t1 = fminf(fminf(fmaxf(tx, bx), fmaxf(ty, by)), fmaxf(tz, bz));
-                }
-                if (t1 > t0) {
-                    const float *data = m.grids + sdf.dataOff;
-                    auto eval = [&](float tt) -> float {
-                        f3 xf, xg;
-                        xf.x = dn.x * tt + of.x; xf.y = dn.y * tt + of.y; xf.z = dn.z * tt + of.z;
-                        xg.x = fmaxf(1.0f, fminf((xf.x - sdf.ox) / sdf.res, hix));
-                        xg.y = fmaxf(1.0f, fminf((xf.y - sdf.oy) / sdf.res, hiy));
-                        xg.z = fmaxf(1.0f, fminf((xf.z - sdf.oz) / sdf.res, hiz));
-                        return grid_value(data, sdf.dimx, sdf.dimy, xg) * sdf.res;
-                    };
-                    float sdfValPrev = eval(t0);
-                    float tPrev = t0;
-                    const float minStep = sdf.res / 10;
-                    while (t0 < t1 && t0 < limitT) {
-                        const float sdfVal = eval(t0);
-                        if (sdfValPrev > levelSet && sdfVal <= levelSet) {
-                            det = t0;
-                            hit = (t0 - tPrev) * (levelSet - sdfValPrev) / (sdfVal - sdfValPrev) + tPrev;
-                            break;                  // the reference's loop ends here too: closestT = hit <= t0 < next t0
-                        }
-                        sdfValPrev = sdfVal;
-                        tPrev = t0;
-                        t0 += fmaxf(minStep, fabsf(sdfVal));
-                    }
-                }
+                closestT = tHit;
             }
-            sDet[wave * 64 + lane] = det;
-            sHit[wave * 64 + lane] = hit;
-        }
-        __syncthreads();
-        if (wave == 0 && valid) {       // sequential rule of the reference over this round's SDFs
-            for (int k = 0; k < nc; ++k) {
-                const float det = sDet[k * 64 + lane];
-                if (det < closestT) {
-                    const float tHit = sHit[k * 64 + lane];
-                    const float *T_fc = sT + 24 * k;
-                    const f3 of = se3_apply_w(T_fc, 0.f, 0.f, 0.f, 1.f);
-                    const f3 df = se3_apply_w(T_fc, rd.x, rd.y, rd.z, 0.f);
-                    const float inv = 1.0f / sqrtf(df.x * df.x + df.y * df.y + df.z * df.z);
-                    const float dnx = df.x * inv, dny = df.y * inv, dnz = df.z * inv;
-                    const f3 xc = se3_apply_w(T_fc + 12, dnx * tHit + of.x, dny * tHit + of.y, dnz * tHit + of.z, 1.0f);
-                    if (pr.z == 0 || xc.z < pr.z) {
-                        pr.x = xc.x; pr.y = xc.y; pr.z = xc.z; pr.w = (float)((modelNum << 16) + s0 + k);
-                    }
-                    closestT = tHit;
-                }
-            }
-            sClosest[lane] = closestT;
         }
     }
-    if (wave == 0 && valid) prediction[index] = pr;
+    if (valid) prediction[index] = pr;
+}
+
+static int launch_raycast(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
+                          float *d_prediction, float levelSet, hipStream_t st) {
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    const size_t nPix = (size_t)width * height;
+    rc = ensure_ray_buf(ws, 2 * nPix * (size_t)m.nSdfs);
+    if (rc) return rc;
+    const long long tasks = (long long)((width + 7) / 8) * ((height + 7) / 8) * m.nSdfs;
+    DARTK_REQUIRE(tasks < (1ll << 31), "ray-cast of %dx%d against %d SDFs exceeds the launch limits", width, height, m.nSdfs);
+    hipLaunchKernelGGL(raycast_trace_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height, m,
+                       (float2 *)ws->rayBuf, levelSet);
+    hipLaunchKernelGGL(raycast_replay_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height,
+                       modelNum, m, (const float2 *)ws->rayBuf, (float4 *)d_prediction);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
 }
 
 // gpu_cullUnobservable, modToObs.cu:682-709
@@ -422,11 +448,7 @@ int gn_launch_ne_mod2obs(const float *d_pred, int width, int height, const Model
 }
 int gn_launch_raycast(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                       float *d_prediction, hipStream_t st) {
-    const int tiles = ((width + 7) / 8) * ((height + 7) / 8);
-    hipLaunchKernelGGL(raycast_prediction_kernel, dim3(tiles), dim3(64 * RC_WAVES), 0, st,
-                       flx, fly, ppx, ppy, width, height, modelNum, m, (float4 *)d_prediction, 0.0f);
-    DARTK_HIP(hipGetLastError());
-    return DARTK_OK;
+    return launch_raycast(flx, fly, ppx, ppy, width, height, modelNum, m, d_prediction, 0.0f, st);
 }
 int gn_launch_cull(float *d_pred, int pw, int ph, const float *d_obs, int ow, int oh, hipStream_t st) {
     hipLaunchKernelGGL(cull_unobservable_kernel, dim3((pw * ph + 255) / 256), dim3(256), 0, st, (float4 *)d_pred, pw, ph,
@@ -481,11 +503,7 @@ int dartk_raycast_prediction(float flx, float fly, float ppx, float ppy, int wid
     DARTK_REQUIRE(mod && d_prediction, "dartk_raycast_prediction: null argument");
     DARTK_REQUIRE(width > 0 && height > 0 && flx != 0 && fly != 0, "bad camera %dx%d f=(%g,%g)", width, height, flx, fly);
     DARTK_REQUIRE(modelNum >= 0 && modelNum < 32768, "modelNum %d out of range", modelNum);
-    const int tiles = ((width + 7) / 8) * ((height + 7) / 8);
-    hipLaunchKernelGGL(raycast_prediction_kernel, dim3(tiles), dim3(64 * RC_WAVES), 0,
-                       as_stream(stream), flx, fly, ppx, ppy, width, height, modelNum, mod->v, (float4 *)d_prediction, levelSet);
-    DARTK_HIP(hipGetLastError());
-    return DARTK_OK;
+    return launch_raycast(flx, fly, ppx, ppy, width, height, modelNum, mod->v, d_prediction, levelSet, as_stream(stream));
 }
 
 int dartk_cull_unobservable(float *d_pred, int pw, int ph, const float *d_obs, int ow, int oh, void *stream) {

@@ -35,6 +35,11 @@ int get_workspace(Workspace **out) {
         DARTK_HIP(hipMalloc((void **)&w.partials, w.partialFloats * sizeof(float)));
         DARTK_HIP(hipMalloc((void **)&w.counters, 64 * sizeof(int)));
         DARTK_HIP(hipMalloc((void **)&w.sysScratch, (size_t)8 * kMaxSys * sizeof(float)));
+        w.rayBuf = nullptr; w.rayFloats = 0;
+        w.validIdx = nullptr; w.validInts = 0;
+        DARTK_HIP(hipStreamCreateWithFlags(&w.auxStream, hipStreamNonBlocking));
+        DARTK_HIP(hipEventCreateWithFlags(&w.evFork, hipEventDisableTiming));
+        DARTK_HIP(hipEventCreateWithFlags(&w.evJoin, hipEventDisableTiming));
         g_ws_ready[dev] = true;
     }
     *out = &g_ws[dev];
@@ -62,6 +67,26 @@ int ensure_partials(Workspace *w, size_t floats) {
     DARTK_HIP(hipFree(w->partials));
     w->partialFloats = floats;
     DARTK_HIP(hipMalloc((void **)&w->partials, floats * sizeof(float)));
+    return DARTK_OK;
+}
+
+int ensure_ray_buf(Workspace *w, size_t floats) {
+    if (floats <= w->rayFloats) return DARTK_OK;
+    DARTK_HIP(hipDeviceSynchronize());
+    if (w->rayBuf) DARTK_HIP(hipFree(w->rayBuf));
+    w->rayBuf = nullptr; w->rayFloats = 0;
+    DARTK_HIP(hipMalloc((void **)&w->rayBuf, floats * sizeof(float)));
+    w->rayFloats = floats;
+    return DARTK_OK;
+}
+
+int ensure_valid_idx(Workspace *w, size_t ints) {
+    if (ints <= w->validInts) return DARTK_OK;
+    DARTK_HIP(hipDeviceSynchronize());
+    if (w->validIdx) DARTK_HIP(hipFree(w->validIdx));
+    w->validIdx = nullptr; w->validInts = 0;
+    DARTK_HIP(hipMalloc((void **)&w->validIdx, ints * sizeof(int)));
+    w->validInts = ints;
     return DARTK_OK;
 }
 
