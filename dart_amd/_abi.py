@@ -39,6 +39,20 @@ class OptOptions(C.Structure):
                 ("predWidth", C.c_int32), ("predHeight", C.c_int32), ("predFl", C.c_float * 2)]
 
 
+class ContactPriorC(C.Structure):
+    """dartk_contact_prior (include/dartk.h); orc_contact_prior has the same layout."""
+    _fields_ = [("srcModel", C.c_int32), ("dstModel", C.c_int32), ("srcSdf", C.c_int32), ("weight", C.c_float),
+                ("contactPoint", C.c_float * 3), ("normal", C.c_float * 3), ("invert", C.c_int32),
+                ("contactThreshold", C.c_float), ("updateSrc", C.c_int32), ("updateDst", C.c_int32),
+                ("updateContact", C.c_int32)]
+
+
+class NoObsOptions(C.Structure):
+    """dartk_noobs_options (include/dartk.h); orc_noobs_options has the same layout."""
+    _fields_ = [("numIterations", C.c_int32), ("nModels", C.c_int32), ("regularization", C.c_float * 8),
+                ("regularizationScaled", C.c_float * 8), ("lambdaIntersection", C.c_float * 64)]
+
+
 def fptr(a):
     return a.ctypes.data_as(c_float_p)
 
@@ -133,6 +147,12 @@ def lib():
         "dartk_depth_to_vertices": [vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp],
         "dartk_vertices_to_normals": [vp, vp, C.c_int, C.c_int, vp],
         "dartk_prediction_to_depth": [vp, vp, C.c_int, C.c_int, vp],
+        "dartk_noobs_create": [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(vp), c_float_p,
+                               C.POINTER(ContactPriorC), C.c_int, C.c_int, C.POINTER(vp)],
+        "dartk_noobs_destroy": [vp],
+        "dartk_noobs_set_priors": [vp, C.POINTER(ContactPriorC), C.c_int, vp],
+        "dartk_noobs_optimize_poses": [vp, C.POINTER(NoObsOptions), C.c_int, vp, vp, vp, vp, vp, vp],
+        "dartk_noobs_get_error": [vp, C.POINTER(NoObsOptions), C.c_int, vp, vp, vp, vp],
         "dartk_profile_begin": [],
         "dartk_profile_end": [c_float_p, c_int_p],
         "dartk_optimize_pose": [vp, vp, vp, C.c_int, C.c_int, C.POINTER(OptOptions), vp, C.c_int, vp, vp, vp, vp, vp],

@@ -90,3 +90,156 @@ def config2(width=640, height=480):
 def config2_left_hand(width=640, height=480):
     """The asset-faithful articulated model (primitives straight from models/leftHand/leftHand.xml)."""
     return _articulated("C2-leftHand", "left_hand", width, height, 0.45, np.random.default_rng(SEED + 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ContactGrasp (BASELINE configs 3 / 4): HumanHand + object, attractive / repulsive contact points + thumb prior.
+# ---------------------------------------------------------------------------------------------------------------------
+@dataclass
+class GraspScene:
+    name: str
+    hand: object                 # voxelised HostModel (model 0 = hand_id, grasp_analyzer.cpp:204)
+    obj: object                  # voxelised HostModel (model 1 = object_id)
+    potential: np.ndarray        # hand self-intersection potential matrix [nSdfs*nSdfs]
+    priors: list                 # tracker_no_obs.ContactPrior
+    gt_T_mc: np.ndarray          # "ground truth" hand pose the contact map was painted from
+    gt_joints: np.ndarray
+    init_T_mc: np.ndarray        # [B, 12] candidate hand poses
+    init_joints: np.ndarray      # [B, nJ]
+    num_iterations: int
+    lambda_intra: float
+    lambda_inter: float
+    lm_damping: float
+    regularization: float
+
+
+OBJ_RADII = (0.045, 0.035, 0.06)    # ellipsoid "object" (the reference's object meshes are not in its tree)
+
+
+def _object_model():
+    from .model import HostModel, GEOM_SPHERE
+    m = HostModel(version=1, name="object")
+    m._geom_specs = [{"frame": 0, "type": GEOM_SPHERE, "scale": list(OBJ_RADII), "trans": [0, 0, 0], "rot": [0, 0, 0]}]
+    m.add_geometry(0, GEOM_SPHERE, list(OBJ_RADII), [0, 0, 0], [0, 0, 0])
+    return m.voxelize(0.005, 0.10)
+
+
+def _hand_potential(asset, n):
+    import json
+    import os
+    from .model import ASSET_DIR
+    spec = json.load(open(os.path.join(ASSET_DIR, asset + ".json")))
+    pot = np.zeros((n, n), dtype=np.int32)
+    mat = np.asarray(spec["intersection_potential"], dtype=np.int32)
+    k = min(n, mat.shape[0])
+    pot[:k, :k] = mat[:k, :k]
+    return pot.reshape(-1), spec.get("thumb")
+
+
+def contact_grasp_scene(n_candidates=1, asset="human_hand", n_attract=500, n_repulse=2000, iterations=40, seed=SEED):
+    """GraspAnalyser's cost set-up (grasp_analyzer.cpp:198-204, 248-389, 941-1008) on synthetic contact data: the object
+    sits at the origin of the camera frame, the contact map is "painted" by a ground-truth grasp (object surface points
+    within 1 cm of the posed hand are contact points, the rest non-contact points, outward normals), the candidates are
+    seeded perturbations of that grasp."""
+    from scipy.spatial import cKDTree
+    from .tracker_no_obs import ContactPrior
+    rng = np.random.default_rng(seed)
+    hand = load_asset(asset).voxelize(0.005, 0.10)
+    obj = _object_model()
+    pot, thumb = _hand_potential(asset, len(hand.sdfs))
+    lim = np.asarray(hand.joint_limits, dtype=np.float64).reshape(-1, 2)
+    # palm below the object, fingers curling around it: for a few finger-flexion levels slide the palm along the
+    # approach axis until the hand's collision cloud just touches the ellipsoid, and keep the grasp whose links touch most
+    cloud = hand.collision_cloud(1e5, seed=1)
+    a = np.asarray(OBJ_RADII, dtype=np.float64)
+    best = (-1, None, None)
+    for flex in (0.25, 0.35, 0.45, 0.55, 0.65):
+        jt = (lim[:, 0] + (lim[:, 1] - lim[:, 0]) * flex).astype(F)
+        T_mf = hand.forward_kinematics(jt, "dh")
+        sdf_of = cloud[:, 3].astype(int)
+        pts_m = np.zeros((len(cloud), 3), dtype=F)
+        for sn in np.unique(sdf_of):
+            sel = sdf_of == sn
+            pts_m[sel] = se3.apply(T_mf[hand.sdf_frame[int(sn)]], cloud[sel, :3])
+        prev = None
+        # HumanHand: palm at x ~ -0.08, fingers along -x, flexion curls them towards -y: the object approaches from -y
+        for dist in np.arange(0.20, 0.0, -0.002):
+            T_try = se3.translation(0.125, dist, 0.0)       # model -> camera (object frame)
+            pc = se3.apply(T_try, pts_m).astype(np.float64)
+            lvl = np.sqrt(((pc / a) ** 2).sum(1))
+            if (lvl < 1.0).sum() > 20:
+                break
+            prev = (T_try, pc, lvl)
+        if prev is None:
+            continue
+        T_try, pc, lvl = prev
+        near = np.abs(lvl - 1.0) * a.min() < 0.008
+        score = len(np.unique(sdf_of[near]))
+        if score > best[0]:
+            best = (score, T_try, jt, pts_m)
+    _, T_cm, gt_joints, pts_m = best
+    gt_T_mc = se3.invert(T_cm)
+    # object surface samples + outward normals, split by distance to the posed hand
+    n_s = 20000
+    v = rng.normal(size=(n_s, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    surf = v * a
+    nrm = surf / a ** 2
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    hand_c = se3.apply(T_cm, pts_m.astype(F)).astype(np.float64)
+    d, _ = cKDTree(hand_c).query(surf)
+    contact = np.where(d < 0.012)[0]
+    free = np.where(d >= 0.012)[0]
+    rng.shuffle(contact)
+    rng.shuffle(free)
+    contact, free = contact[:n_attract], free[:n_repulse]
+    att_w, rep_w, thumb_w = 150.0, 20.0, 25.0      # after the GUI setters ran (undivided, grasp_analyzer.cpp:941-965)
+    thr = 0.02
+    priors = []
+    for i in contact:      # ContactPrior(object_id, hand_id, 0, -1, w, p, false, true, true, false, thr, n)
+        priors.append(ContactPrior(1, 0, 0, -1, att_w, tuple(surf[i].astype(F)), False, True, True, False, thr, tuple(nrm[i].astype(F))))
+    for i in free:
+        priors.append(ContactPrior(1, 0, 0, -1, rep_w, tuple(surf[i].astype(F)), False, True, True, True, thr, tuple(nrm[i].astype(F))))
+    if thumb is not None:  # ContactPrior(hand_id, object_id, thumb_frame_id, 0, w, thumb_point, false, true, true, false, thr)
+        priors.append(ContactPrior(0, 1, int(thumb["sdf"]), 0, thumb_w, tuple(thumb["point"]), False, True, True, False, thr))
+    # candidates: candidate 0 = a mild perturbation (C3), the rest +-3 cm / +-20 deg / joints uniform in limits (C4)
+    Ts, Js = [], []
+    for c in range(n_candidates):
+        if c == 0:
+            T, j = _perturb(gt_T_mc, gt_joints.astype(np.float64), lim, rng, 0.01, 5.0, 0.1)
+        else:
+            T, _ = _perturb(gt_T_mc, gt_joints.astype(np.float64), lim, rng, 0.03 * rng.random(), 20.0 * rng.random(), 0.0)
+            j = (lim[:, 0] + (lim[:, 1] - lim[:, 0]) * rng.random(len(lim))).astype(F)
+        Ts.append(T)
+        Js.append(j)
+    return GraspScene("C3-contactgrasp" if n_candidates == 1 else "C4-contactgrasp-batch", hand, obj, pot, priors, gt_T_mc, gt_joints,
+                      np.stack(Ts).astype(F), np.stack(Js).astype(F), iterations, 5.0, 100.0, 25.0, float(F(10.0) ** F(-7.5)))
+
+
+def make_grasp_tracker(sc, max_batch=1):
+    """create_tracker() + load_object() + the option setters (grasp_analyzer.cpp:392-436, 248-389, 936-1008)."""
+    from .tracker_no_obs import TrackerNoObs
+    tr = TrackerNoObs(max_batch=max_batch)
+    hand_id = tr.addModel(sc.hand, cloud_seed=11)
+    tr.setIntersectionPotentialMatrix(hand_id, sc.potential)
+    obj_id = tr.addModel(sc.obj, cloud_seed=12)
+    for p in sc.priors:
+        tr.addPrior(p)
+    n = tr.getNumModels()
+    o = tr.getOptions()
+    o.numIterations = sc.num_iterations
+    o.lambdaIntersection[hand_id + n * hand_id] = sc.lambda_intra
+    o.lambdaIntersection[obj_id + n * hand_id] = sc.lambda_inter
+    o.lambdaIntersection[hand_id + n * obj_id] = sc.lambda_inter
+    o.regularization = [sc.regularization] * n
+    o.regularizationScaled = [sc.lm_damping] * n
+    return tr
+
+
+def grasp_batch_arrays(sc):
+    """[B, 2, 12] camera->model transforms (hand, object = identity) and [B, nJ] joints of the candidates."""
+    B = len(sc.init_T_mc)
+    T = np.zeros((B, 2, 12), dtype=F)
+    T[:, 0] = sc.init_T_mc
+    T[:, 1] = se3.identity()
+    return T, sc.init_joints.copy()

@@ -87,6 +87,33 @@ __device__ __forceinline__ bool normal_test(const ModelView &m, const AssocResul
     return true;
 }
 
+struct Collision {
+    bool hit;
+    int dstGrid;
+    float residual;
+    f3 vg;        // grid coordinates in the penetrated SDF
+};
+
+// First penetrated destination SDF of a point given in the destination model's frame
+// (intersection.cu:100-142 / :405-441). pot == nullptr means "test every SDF" (inter-model case).
+__device__ __forceinline__ Collision first_collision(const ModelView &dst, const float *T_fm_dst, f3 v_dm,
+                                                     const int *__restrict__ pot, int srcGrid) {
+    Collision c;
+    c.hit = false; c.dstGrid = -1; c.residual = 0.0f; c.vg.x = c.vg.y = c.vg.z = 0.0f;
+    const int n = dst.nSdfs;
+    for (int g = 0; g < n; ++g) {
+        if (pot && !pot[g + srcGrid * n]) continue;
+        const int f = dst.sdfFrame[g];
+        const f3 vd = se3_apply_w(T_fm_dst + 12 * f, v_dm.x, v_dm.y, v_dm.z, 1.0f);
+        const SdfDev &s = dst.sdfs[g];
+        const f3 vg = grid_coords(s, vd);
+        if (!in_bounds_grad_interp(s, vg)) continue;
+        const float r = grid_value(dst.grids + s.dataOff, s.dimx, s.dimy, vg) * s.res;
+        if (r < 0) { c.hit = true; c.dstGrid = g; c.residual = r; c.vg = vg; break; }
+    }
+    return c;
+}
+
 // Copy the pose-dependent transforms and the SDF header table into LDS (once per workgroup); used where the
 // frame / SDF index differs per lane.
 __device__ __forceinline__ void stage_model(const ModelView &m, float *sT_fm, float *sT_mf, SdfDev *sSdf) {

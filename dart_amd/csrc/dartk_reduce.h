@@ -30,9 +30,11 @@ struct PairAcc {
     float acc[PPT];
     int ia[PPT], ib[PPT];
 
-    __device__ __forceinline__ void init(int d, bool drop) {
+    // drop: J^T J from the second copy of the row (both factors); weighted: first factor from the second copy
+    // (w*J), second from the plain row (ContactPrior's w*J*J^T, contact_prior.cpp:129)
+    __device__ __forceinline__ void init(int d, bool drop, bool weighted = false) {
         const int S = sys_size(d);
-        const int base = drop ? d + 3 : 0;
+        const int base = (drop || weighted) ? d + 3 : 0;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int o = (int)threadIdx.x + k * BLOCK;
@@ -46,7 +48,8 @@ struct PairAcc {
                 while (((i * (i + 1)) >> 1) > t) --i;
                 while ((((i + 1) * (i + 2)) >> 1) <= t) ++i;
                 const int j = t - ((i * (i + 1)) >> 1);
-                a = base + i; b = base + j;
+                if (weighted) { a = base + j; b = i; }
+                else { a = base + i; b = base + j; }
             }
             ia[k] = a; ib[k] = b;
         }
@@ -72,6 +75,13 @@ struct PairAcc {
 #pragma unroll
             for (int k = 0; k < PPT; ++k) acc[k] = __builtin_fmaf(r0[ia[k]], r0[ib[k]], acc[k]);
         }
+    }
+
+    // add v to output slot o (by the thread that owns it)
+    __device__ __forceinline__ void add_at(int o, double v) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            if ((int)threadIdx.x + k * BLOCK == o) acc[k] = (float)((double)acc[k] + v);
     }
 
     __device__ __forceinline__ void store(float *slab, int S) const {

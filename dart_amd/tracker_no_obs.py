@@ -1,0 +1,235 @@
+"""dart::TrackerNoObs + dart::ContactPrior (src/tracker_no_obs.{h,cpp}, src/optimization/priors.h) -- host mirror.
+
+The per-iteration work of OptimizerNoObs::optimizePoses / getError runs in libdartk (dartk_noobs_*): intersection
+terms, every contact prior, the solve and the pose update stay on the device, for one pose set or for a batch of
+independent candidates (ContactGrasp's grasp list, grasp_analyzer.cpp:851-902)."""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+import torch
+
+from . import _abi, device, se3
+from ._abi import check, lib
+from .optimizer import OptimizationOptions
+
+F = np.float32
+
+
+@dataclass
+class ContactPrior:
+    """ContactPrior constructor arguments (priors.h:38-49)."""
+    srcModelID: int
+    dstModelID: int
+    srcSdfNum: int
+    dstSdfNum: int          # ignored: reset to "nearest" before every evaluation (optimizer.cpp:914)
+    weight: float
+    contactPoint: tuple
+    update_contact_point: bool = True
+    update_src_pose: bool = True
+    update_dst_pose: bool = True
+    invert: bool = False
+    contactThreshold: float = -1.0
+    normal_sf: tuple = (0.0, 0.0, 0.0)
+
+    def setWeight(self, w):
+        self.weight = float(w)
+
+    def setContactThreshold(self, t):
+        self.contactThreshold = float(t)
+
+    def isInverted(self):
+        return self.invert
+
+    def fill(self, c):
+        c.srcModel, c.dstModel, c.srcSdf = int(self.srcModelID), int(self.dstModelID), int(self.srcSdfNum)
+        c.weight = float(self.weight)
+        for k in range(3):
+            c.contactPoint[k] = float(self.contactPoint[k])
+            c.normal[k] = float(self.normal_sf[k])
+        c.invert = int(bool(self.invert))
+        c.contactThreshold = float(self.contactThreshold)
+        c.updateSrc, c.updateDst, c.updateContact = int(self.update_src_pose), int(self.update_dst_pose), int(self.update_contact_point)
+        return c
+
+
+def priors_array(priors, cls=None):
+    cls = cls or _abi.ContactPriorC
+    arr = (cls * max(len(priors), 1))()
+    for i, p in enumerate(priors):
+        p.fill(arr[i])
+    return arr
+
+
+class TrackerNoObs:
+    """TrackerNoObs (tracker_no_obs.h:23-110): models, poses, collision clouds, potential matrices, priors, options."""
+
+    def __init__(self, max_batch=1):
+        self.models: List[device.DeviceModel] = []
+        self.host_models = []
+        self.clouds = []
+        self.potentials = []
+        self.T_mc = []          # per model, camera->model (Pose::getTransformCameraToModel)
+        self.joints = []
+        self.priors: List[ContactPrior] = []
+        self.opts = OptimizationOptions()
+        self.opts.lambdaIntersection = []
+        self.opts.regularization = []
+        self.opts.regularizationScaled = []
+        self.max_batch = max_batch
+        self._handle = None
+        self._terms_key = None
+
+    # ---- TrackerNoObs::addModel (tracker_no_obs.cpp:58-235): voxelised host model -> device mirror + collision cloud
+    def addModel(self, host_model, collision_cloud_density=1e5, cloud_seed=0):
+        m_id = len(self.models)
+        dm = device.DeviceModel(host_model, model_id=m_id)
+        self.models.append(dm)
+        self.host_models.append(host_model)
+        cloud = host_model.collision_cloud(collision_cloud_density, seed=cloud_seed)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.clouds.append(torch.from_numpy(np.ascontiguousarray(cloud, dtype=F)).to(dev))
+        n = len(host_model.sdfs)
+        self.potentials.append(torch.ones(n * n, dtype=torch.int32, device=dev))
+        self.T_mc.append(se3.identity())
+        self.joints.append(np.zeros(host_model.n_joints, dtype=F))
+        n_models = len(self.models)
+        # option vectors grow with the models (tracker_no_obs.cpp:219-229)
+        old = self.opts.lambdaIntersection
+        lam = [0.0] * (n_models * n_models)
+        for s in range(n_models - 1):
+            for d in range(n_models - 1):
+                lam[s + d * n_models] = old[s + d * (n_models - 1)]
+        self.opts.lambdaIntersection = lam
+        self.opts.regularization.append(self.opts.regularization[0] if self.opts.regularization else 1e-20)
+        self.opts.regularizationScaled.append(self.opts.regularizationScaled[0] if self.opts.regularizationScaled else 1.0)
+        self._handle = None
+        return m_id
+
+    def getNumModels(self):
+        return len(self.models)
+
+    def getOptions(self):
+        return self.opts
+
+    def setIntersectionPotentialMatrix(self, model_num, matrix):
+        n = len(self.host_models[model_num].sdfs)
+        mat = np.ascontiguousarray(matrix, dtype=np.int32).reshape(-1)
+        assert mat.size == n * n
+        self.potentials[model_num] = torch.from_numpy(mat).to(self.clouds[model_num].device)
+        self._handle = None
+
+    def addPrior(self, prior):
+        self.priors.append(prior)
+        self._handle = None
+
+    def setPose(self, model_num, T_mc, joints):
+        self.T_mc[model_num] = np.ascontiguousarray(T_mc, dtype=F).reshape(12)
+        self.joints[model_num] = np.ascontiguousarray(joints, dtype=F).reshape(-1)
+
+    # ---- device state
+    def _options_struct(self, cls=None):
+        o = (cls or _abi.NoObsOptions)()
+        n = len(self.models)
+        o.numIterations, o.nModels = int(self.opts.numIterations), n
+        for m in range(n):
+            o.regularization[m] = self.opts.regularization[m]
+            o.regularizationScaled[m] = self.opts.regularizationScaled[m]
+        for i in range(n * n):
+            o.lambdaIntersection[i] = self.opts.lambdaIntersection[i]
+        return o
+
+    def _ensure(self, batch):
+        n = len(self.models)
+        key = (tuple(v > 0 for v in self.opts.lambdaIntersection), len(self.priors), max(batch, self.max_batch))
+        if self._handle is not None and key == self._terms_key:
+            return
+        self.close()
+        self.max_batch = key[2]
+        handles = (C.c_void_p * n)(*[m.handle for m in self.models])
+        clouds = (C.c_void_p * n)(*[C.c_void_p(c.data_ptr()) for c in self.clouds])
+        counts = (C.c_int32 * n)(*[int(c.shape[0]) for c in self.clouds])
+        pots = (C.c_void_p * n)(*[C.c_void_p(p.data_ptr()) for p in self.potentials])
+        lam = (C.c_float * (n * n))(*self.opts.lambdaIntersection)
+        arr = priors_array(self.priors)
+        h = C.c_void_p()
+        check(lib().dartk_noobs_create(n, handles, clouds, counts, pots, lam, arr, len(self.priors), self.max_batch, C.byref(h)))
+        self._handle = h
+        self._terms_key = key
+        self._priors_sig = self._sig()
+
+    def _sig(self):
+        return [(p.weight, tuple(p.contactPoint), p.contactThreshold) for p in self.priors]
+
+    def _sync_priors(self):
+        if self._priors_sig != self._sig():
+            arr = priors_array(self.priors)
+            check(lib().dartk_noobs_set_priors(self._handle, arr, len(self.priors), device._stream()))
+            self._priors_sig = self._sig()
+
+    def close(self):
+        if self._handle is not None:
+            lib().dartk_noobs_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- TrackerNoObs::optimizePoses (tracker_no_obs.cpp:271-299)
+    def optimizePoses(self, debug=False):
+        """Refines the tracker's current poses in place; returns OptimizerNoObs::getError at the result."""
+        T = np.stack(self.T_mc).astype(F)[None]
+        j = np.concatenate(self.joints).astype(F)[None] if sum(len(x) for x in self.joints) else np.zeros((1, 1), dtype=F)
+        T_out, j_out, energy, info, first = self.optimizePosesBatch(T, j, debug=debug)
+        off = 0
+        for m in range(len(self.models)):
+            self.T_mc[m] = T_out[0, m].copy()
+            nj = len(self.joints[m])
+            self.joints[m] = j_out[0, off:off + nj].copy()
+            off += nj
+        self.iter_info, self.first_system = (info[0] if info is not None else None), (first[0] if first is not None else None)
+        return float(energy[0])
+
+    def optimizePosesBatch(self, T_mcs, joints, debug=False, device_arrays=False):
+        """`batch` independent candidates: T_mcs [B, nModels, 12], joints [B, sum of joints] (numpy or CUDA tensors).
+        Returns (T_mcs, joints, energy[B], iter_info, first_system)."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        T = torch.as_tensor(T_mcs, dtype=torch.float32, device=dev).contiguous().clone()
+        j = torch.as_tensor(joints, dtype=torch.float32, device=dev).contiguous().clone()
+        B = T.shape[0]
+        self._ensure(B)
+        self._sync_priors()
+        o = self._options_struct()
+        energy = torch.empty(B, dtype=torch.float32, device=dev)
+        D = sum(m.dims for m in self.models)
+        info = first = None
+        if debug:
+            info = torch.zeros((B, max(o.numIterations, 1), 8), dtype=torch.float32, device=dev)
+            first = torch.zeros((B, D * D + D), dtype=torch.float32, device=dev)
+        check(lib().dartk_noobs_optimize_poses(self._handle, C.byref(o), B, device._ptr(T), device._ptr(j), device._ptr(energy),
+                                               device._ptr(info), device._ptr(first), device._stream()))
+        if device_arrays:
+            return T, j, energy, info, first
+        return (T.cpu().numpy(), j.cpu().numpy(), energy.cpu().numpy(), None if info is None else info.cpu().numpy(),
+                None if first is None else first.cpu().numpy())
+
+    def getError(self, T_mcs=None, joints=None):
+        """OptimizerNoObs::getError for the tracker's poses (or a batch)."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if T_mcs is None:
+            T_mcs = np.stack(self.T_mc).astype(F)[None]
+            joints = np.concatenate(self.joints).astype(F)[None] if sum(len(x) for x in self.joints) else np.zeros((1, 1), dtype=F)
+        T = torch.as_tensor(T_mcs, dtype=torch.float32, device=dev).contiguous()
+        j = torch.as_tensor(joints, dtype=torch.float32, device=dev).contiguous()
+        B = T.shape[0]
+        self._ensure(B)
+        self._sync_priors()
+        o = self._options_struct()
+        energy = torch.empty(B, dtype=torch.float32, device=dev)
+        check(lib().dartk_noobs_get_error(self._handle, C.byref(o), B, device._ptr(T), device._ptr(j), device._ptr(energy), device._stream()))
+        e = energy.cpu().numpy()
+        return float(e[0]) if B == 1 else e

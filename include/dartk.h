@@ -217,6 +217,54 @@ int dartk_optimize_pose(dartk_model_t m, const float *d_vert, const float *d_nor
                         const int32_t *d_potentialIntersection, float *d_prediction, float *d_iterInfo,
                         float *d_firstSystem, void *stream);
 
+/* ------------------------------------------------------------------ ContactGrasp refinement (TrackerNoObs / OptimizerNoObs) */
+/* ContactPrior (optimization/priors.h:35-91): contact point in the source SDF's frame, attracted to (or, inverted,
+ * repelled from) the nearest SDF of the destination model. */
+typedef struct {
+    int32_t srcModel, dstModel, srcSdf;   /* _srcModelID, _dstModelID, _srcSdfNum (dst SDF: nearest, reset every evaluation, optimizer.cpp:914) */
+    float weight;                         /* _weight */
+    float contactPoint[3];                /* _contactPoint (source SDF frame) */
+    float normal[3];                      /* _normal_sf */
+    int32_t invert;                       /* repulsive */
+    float contactThreshold;               /* _contactThreshold */
+    int32_t updateSrc, updateDst, updateContact;   /* updateContact must be 0 on the device path (grasp_analyzer.cpp:359,374,383) */
+} dartk_contact_prior;
+
+/* The OptimizationOptions fields OptimizerNoObs reads (optimization.h:9-72), per model. */
+typedef struct {
+    int32_t numIterations, nModels;
+    float regularization[DARTK_MAX_MODELS];
+    float regularizationScaled[DARTK_MAX_MODELS];
+    float lambdaIntersection[DARTK_MAX_MODELS * DARTK_MAX_MODELS];   /* [src + dst*nModels], optimizer.cpp:866,873 */
+} dartk_noobs_options;
+
+typedef struct dartk_noobs_s *dartk_noobs_t;
+
+/* TrackerNoObs state for one set of models (tracker_no_obs.cpp:58-235, 271-299): collision clouds (float4, xyz in the
+ * owning SDF's frame, w = SDF number), intersection-potential matrices, contact priors, and a pose / partial-system
+ * workspace for up to maxBatch independent candidates. Model m has model ID m. The intersection terms that exist
+ * (lambdaIntersection > 0) are fixed here; their values may change per call. Damping matrices are zero
+ * (tracker_no_obs.cpp:214-215). */
+int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *const *d_collisionClouds,
+                       const int32_t *nCloudPoints, const int32_t *const *d_potentialIntersection,
+                       const float *h_lambdaIntersection, const dartk_contact_prior *h_priors, int nPriors, int maxBatch,
+                       dartk_noobs_t *out);
+int dartk_noobs_destroy(dartk_noobs_t t);
+/* ContactPrior::setWeight / setContactThreshold / contact point resets (priors.h:66-67, grasp_analyzer.cpp:941-981) */
+int dartk_noobs_set_priors(dartk_noobs_t t, const dartk_contact_prior *h_priors, int nPriors, void *stream);
+/* OptimizerNoObs::optimizePoses (optimizer.h:141-160 / optimizer.cpp:783-983) for `batch` independent candidates
+ * (NullReduction poses): per iteration self- and pairwise intersection terms, every contact prior
+ * (ContactPrior::computeContribution, contact_prior.cpp:8-205), regularisation + LM damping after the priors, the
+ * upper-triangular back substitution, pose update; then getError (optimizer.cpp:985-1076) -> d_energy[batch].
+ * d_T_mcs: [batch][nModels][12] camera->model, in/out. d_joints: [batch][sum of joints] in/out (model order).
+ * Optional d_iterInfo [batch][numIterations][8] = {intersection e, sum of prior _error, energy, 0...};
+ * d_firstSystem [batch][D*D + D] = upper JTJ and JTe of iteration 0 before regularisation, D = sum of model dims. */
+int dartk_noobs_optimize_poses(dartk_noobs_t t, const dartk_noobs_options *opts, int batch, float *d_T_mcs,
+                               float *d_joints, float *d_energy, float *d_iterInfo, float *d_firstSystem, void *stream);
+/* OptimizerNoObs::getError (optimizer.cpp:985-1076) at the given poses */
+int dartk_noobs_get_error(dartk_noobs_t t, const dartk_noobs_options *opts, int batch, const float *d_T_mcs,
+                          const float *d_joints, float *d_energy, void *stream);
+
 /* ------------------------------------------------------------------ measurement (no reference counterpart) */
 /* Per-kernel-class device time of the Gauss-Newton loops, measured with HIP events recorded on the launch stream
  * around every launch between dartk_profile_begin() and dartk_profile_end(). Used by bench.py's roofline leg;

@@ -105,3 +105,169 @@ void orc_optimize_pose(const orc_model *m, float *T_mc, float *joints, const flo
     }
     free(T_mf); free(T_fm); free(JTJ); free(A); free(eJ); free(dalpha); free(sys); free(pts); free(pred);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * OptimizerNoObs::optimizePoses / getError (optimizer.cpp:783-1076)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int n, D, sys, nPriors;
+    int offs[ORC_MAX_MODELS], dims[ORC_MAX_MODELS];
+    float *T_mf[ORC_MAX_MODELS], *T_fm[ORC_MAX_MODELS], *T_cm[ORC_MAX_MODELS];
+    const float *cT_mc[ORC_MAX_MODELS], *cT_cm[ORC_MAX_MODELS], *cT_fm[ORC_MAX_MODELS], *cT_mf[ORC_MAX_MODELS];
+    int *priorOff;
+} noobs_ctx;
+
+static void noobs_init(noobs_ctx *c, const orc_model *const *models, int n, const orc_contact_prior *priors, int nPriors) {
+    c->n = n; c->D = 0; c->nPriors = nPriors;
+    for (int m = 0; m < n; ++m) {
+        c->offs[m] = c->D; c->dims[m] = 6 + models[m]->n_joints; c->D += c->dims[m];
+        c->T_mf[m] = (float *)malloc(sizeof(float) * 12 * (size_t)models[m]->n_frames);
+        c->T_fm[m] = (float *)malloc(sizeof(float) * 12 * (size_t)models[m]->n_frames);
+        c->T_cm[m] = (float *)malloc(sizeof(float) * 12);
+    }
+    c->priorOff = (int *)malloc(sizeof(int) * (size_t)(nPriors > 0 ? nPriors : 1));
+    int sys = c->D, anyFrozen = 0;
+    for (int p = 0; p < nPriors; ++p) {
+        if (priors[p].updateContact) { c->priorOff[p] = sys; sys += 3; }
+        else { c->priorOff[p] = -1; anyFrozen = 1; }
+    }
+    /* frozen contact points share one all-zero 3-parameter slot (their rows never receive a non-zero) */
+    if (anyFrozen) { for (int p = 0; p < nPriors; ++p) if (c->priorOff[p] < 0) c->priorOff[p] = sys; sys += 3; }
+    c->sys = sys;
+}
+static void noobs_free(noobs_ctx *c) {
+    for (int m = 0; m < c->n; ++m) { free(c->T_mf[m]); free(c->T_fm[m]); free(c->T_cm[m]); }
+    free(c->priorOff);
+}
+static void noobs_set_poses(noobs_ctx *c, const orc_model *const *models, float *const *T_mcs, float *const *joints) {
+    for (int m = 0; m < c->n; ++m) {
+        orc_fk_set_pose(models[m], joints[m], c->T_mf[m], c->T_fm[m]);
+        orc_se3_invert(T_mcs[m], c->T_cm[m]);
+        c->cT_mc[m] = T_mcs[m]; c->cT_cm[m] = c->T_cm[m]; c->cT_fm[m] = c->T_fm[m]; c->cT_mf[m] = c->T_mf[m];
+    }
+}
+
+/* intersection terms of model m into (eJ, JTJ) [dims x dims]; returns the sum of the lambda-scaled errors */
+static float noobs_intersection_terms(noobs_ctx *c, const orc_model *const *models, float *const *T_mcs, int m,
+                                      const orc_noobs_options *o, const float *const *clouds, const int32_t *nClouds,
+                                      const int32_t *const *potentials, float *eJ, float *JTJ, float *sys) {
+    const int n = c->n, dims = c->dims[m], ad = dims - 6;
+    float total = 0.0f;
+    if (o->lambdaIntersection[m + m * n] > 0) { /* computeSelfIntersectionContribution, optimizer.cpp:332-384 */
+        orc_ne_self_intersection(clouds[m], nClouds[m], models[m], c->T_fm[m], c->T_mf[m], potentials[m], 0, dims, NULL, NULL, sys);
+        if (ad > 0) {
+            float *eJt = (float *)calloc((size_t)ad, sizeof(float));
+            float *Jt = (float *)calloc((size_t)ad * ad, sizeof(float));
+            total += orc_unpack(eJt, Jt, ad, sys, o->lambdaIntersection[m + m * n], ad);
+            for (int i = 0; i < ad; ++i) {
+                eJ[6 + i] += eJt[i];
+                for (int j = 0; j < ad; ++j) JTJ[(6 + i) * dims + 6 + j] += Jt[i * ad + j];
+            }
+            free(eJt); free(Jt);
+        }
+    }
+    for (int d = 0; d < n; ++d) { /* computeIntersectionContribution, optimizer.cpp:386-421 */
+        if (d == m || !(o->lambdaIntersection[m + d * n] > 0)) continue;
+        float T_ds[12], T_sd[12];
+        orc_se3_mul(T_mcs[d], c->T_cm[m], T_ds);
+        orc_se3_invert(T_ds, T_sd);
+        orc_ne_intersection(clouds[m], nClouds[m], T_ds, T_sd, models[m], c->T_fm[m], c->T_mf[m], models[d], c->T_fm[d], c->T_mf[d],
+                            0, dims, NULL, NULL, sys);
+        total += orc_unpack(eJ, JTJ, dims, sys, o->lambdaIntersection[m + d * n], dims);
+    }
+    return total;
+}
+
+float orc_get_error_noobs(const orc_model *const *models, float *const *T_mcs, float *const *joints,
+                          const orc_noobs_options *o, const float *const *clouds, const int32_t *nClouds,
+                          const int32_t *const *potentials, const orc_contact_prior *priors, int nPriors) {
+    noobs_ctx c;
+    noobs_init(&c, models, o->nModels, priors, nPriors);
+    noobs_set_poses(&c, models, T_mcs, joints);
+    float error = 0.0f;
+    float *JTJ = (float *)calloc((size_t)c.sys * c.sys, sizeof(float));
+    float *JTe = (float *)calloc((size_t)c.sys, sizeof(float));
+    for (int m = 0; m < c.n; ++m) {
+        const int dims = c.dims[m];
+        float *eJ = (float *)calloc((size_t)dims, sizeof(float));
+        float *J = (float *)calloc((size_t)dims * dims, sizeof(float));
+        float *sys = (float *)malloc(sizeof(float) * (size_t)sys_len(dims));
+        /* getError adds every term's lambda-scaled e (optimizer.cpp:1047,1055) */
+        error += noobs_intersection_terms(&c, models, T_mcs, m, o, clouds, nClouds, potentials, eJ, J, sys);
+        free(eJ); free(J); free(sys);
+    }
+    float pe = 0.0f;
+    for (int p = 0; p < nPriors; ++p)
+        pe += orc_contact_prior_contribution(&priors[p], models, c.cT_mc, c.cT_cm, c.cT_fm, c.cT_mf, c.offs, c.dims, c.priorOff[p],
+                                             JTJ, c.sys, JTe, NULL);
+    if (nPriors > 0) error += pe / (float)nPriors;
+    free(JTJ); free(JTe);
+    noobs_free(&c);
+    return error;
+}
+
+float orc_optimize_poses_noobs(const orc_model *const *models, float *const *T_mcs, float *const *joints,
+                               const orc_noobs_options *o, const float *const *clouds, const int32_t *nClouds,
+                               const int32_t *const *potentials, const orc_contact_prior *priors, int nPriors,
+                               float *iterInfo, float *firstSystem) {
+    noobs_ctx c;
+    noobs_init(&c, models, o->nModels, priors, nPriors);
+    const int sysN = c.sys, D = c.D;
+    float *JTJ = (float *)malloc(sizeof(float) * (size_t)sysN * sysN);
+    float *JTe = (float *)malloc(sizeof(float) * (size_t)sysN);
+    float *x = (float *)malloc(sizeof(float) * (size_t)sysN);
+    for (int it = 0; it < o->numIterations; ++it) {
+        memset(JTJ, 0, sizeof(float) * (size_t)sysN * sysN);
+        memset(JTe, 0, sizeof(float) * (size_t)sysN);
+        noobs_set_poses(&c, models, T_mcs, joints);
+        float eInt = 0.0f, ePri = 0.0f;
+        int nActive = 0;
+        for (int m = 0; m < c.n; ++m) {
+            const int dims = c.dims[m], off = c.offs[m];
+            float *eJ = (float *)calloc((size_t)dims, sizeof(float));
+            float *J = (float *)calloc((size_t)dims * dims, sizeof(float));
+            float *sys = (float *)malloc(sizeof(float) * (size_t)sys_len(dims));
+            eInt += noobs_intersection_terms(&c, models, T_mcs, m, o, clouds, nClouds, potentials, eJ, J, sys);
+            /* symmetrise, += damping (zero), scatter the upper triangle (optimizer.cpp:881-905) */
+            for (int i = 0; i < dims; ++i) for (int j = i; j < dims; ++j)
+                if (J[i * dims + j] != 0) JTJ[(off + i) * sysN + off + j] = J[i * dims + j];
+            for (int i = 0; i < dims; ++i) JTe[off + i] = eJ[i];
+            free(eJ); free(J); free(sys);
+        }
+        for (int p = 0; p < nPriors; ++p) { /* optimizer.cpp:913-916 */
+            int32_t ds = -1;
+            const float e = orc_contact_prior_contribution(&priors[p], models, c.cT_mc, c.cT_cm, c.cT_fm, c.cT_mf, c.offs, c.dims,
+                                                           c.priorOff[p], JTJ, sysN, JTe, &ds);
+            ePri += e;
+            (void)ds;
+        }
+        if (it == 0 && firstSystem) {
+            for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) firstSystem[i * D + j] = JTJ[i * sysN + j];
+            for (int i = 0; i < D; ++i) firstSystem[D * D + i] = JTe[i];
+        }
+        for (int m = 0; m < c.n; ++m) /* optimizer.cpp:919-929 */
+            for (int i = 0; i < c.dims[m]; ++i) {
+                float *d = &JTJ[(c.offs[m] + i) * sysN + c.offs[m] + i];
+                *d += o->regularization[m];
+                *d += o->regularizationScaled[m] * (*d);
+            }
+        orc_solve_upper(JTJ, JTe, sysN, x);
+        for (int i = 0; i < sysN; ++i) x[i] = -x[i];
+        for (int m = 0; m < c.n; ++m) { /* optimizer.cpp:933-954 */
+            float dT[12];
+            orc_se3_exp(x + c.offs[m], dT);
+            orc_se3_mul(dT, T_mcs[m], T_mcs[m]);
+            for (int i = 0; i < models[m]->n_joints; ++i) {
+                const float v = joints[m][i] + x[c.offs[m] + 6 + i];
+                joints[m][i] = fminf(fmaxf(models[m]->joint_limits[2 * i], v), models[m]->joint_limits[2 * i + 1]);
+            }
+        }
+        if (iterInfo) {
+            float *r = iterInfo + 8 * it;
+            r[0] = eInt; r[1] = ePri; r[2] = (float)nActive; r[3] = r[4] = r[5] = r[6] = r[7] = 0;
+        }
+    }
+    free(JTJ); free(JTe); free(x);
+    noobs_free(&c);
+    return orc_get_error_noobs(models, T_mcs, joints, o, clouds, nClouds, potentials, priors, nPriors);
+}

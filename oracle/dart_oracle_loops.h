@@ -26,6 +26,32 @@ void orc_optimize_pose(const orc_model *m, float *T_mc, float *joints, const flo
                        int width, int height, const orc_opt_options *o, const float *cloud, int nCloud,
                        const int32_t *potential, float *obsSdfData, float *iterInfo, float *firstSystem);
 
+/* ---- OptimizerNoObs (ContactGrasp refinement) ---- */
+#define ORC_MAX_MODELS 8
+typedef struct {
+    int32_t numIterations;
+    int32_t nModels;
+    float regularization[ORC_MAX_MODELS];          /* opts.regularization[m] */
+    float regularizationScaled[ORC_MAX_MODELS];    /* opts.regularizationScaled[m] (LM damping) */
+    float lambdaIntersection[ORC_MAX_MODELS * ORC_MAX_MODELS];   /* [src + dst*nModels] (optimizer.cpp:866,873) */
+} orc_noobs_options;
+
+/* OptimizerNoObs::optimizePoses (optimizer.cpp:783-983) for NullReduction poses and zero damping matrices
+ * (tracker_no_obs.cpp:214-215). T_mcs[m] (12 floats) and joints[m] are updated in place; the return value is
+ * getError() (optimizer.cpp:985-1076) at the final poses. Prior-parameter rows exist only for priors with
+ * updateContact set; for the others the reference's rows/columns are identically zero and its triangular solve
+ * skips them (SURVEY A-1/A-7). iterInfo (optional): 8 floats per iteration {sum of intersection e (lambda-scaled),
+ * sum of prior _error, nActivePriors, 0...}. firstSystem (optional): dense upper-triangular JTJ [D*D] followed by
+ * JTe [D] of the first iteration, before regularisation, D = sum of model dims. */
+float orc_optimize_poses_noobs(const orc_model *const *models, float *const *T_mcs, float *const *joints,
+                               const orc_noobs_options *o, const float *const *clouds, const int32_t *nClouds,
+                               const int32_t *const *potentials, const orc_contact_prior *priors, int nPriors,
+                               float *iterInfo, float *firstSystem);
+/* OptimizerNoObs::getError (optimizer.cpp:985-1076) */
+float orc_get_error_noobs(const orc_model *const *models, float *const *T_mcs, float *const *joints,
+                          const orc_noobs_options *o, const float *const *clouds, const int32_t *nClouds,
+                          const int32_t *const *potentials, const orc_contact_prior *priors, int nPriors);
+
 #ifdef __cplusplus
 }
 #endif

@@ -288,3 +288,44 @@ def optimize_pose(om, T_mc, joints, vert, norm, opts_struct, cloud=None, potenti
     lib().orc_optimize_pose(om.ref, f(T), f(j), f(c32(vert)), f(c32(norm)), w, h, C.byref(opts_struct), f(cl), n_cloud, i(pot),
                             f(obs), f(info), f(first))
     return T, j[:om.n_joints], info, first
+
+
+# ---------------------------------------------------------------------------------------------- OptimizerNoObs
+class OrcNoObsOptions(C.Structure):
+    _fields_ = list(_abi.NoObsOptions._fields_)
+
+
+def _noobs_args(oms, T_mcs, joints, clouds, potentials, priors):
+    n = len(oms)
+    models = (C.POINTER(OrcModel) * n)(*[C.pointer(o.desc) for o in oms])
+    T_keep = [c32(T_mcs[m]).copy() for m in range(n)]
+    j_keep = [c32(joints[m]).copy() if oms[m].n_joints else np.zeros(1, dtype=F) for m in range(n)]
+    T_ptrs = (fp * n)(*[f(t) for t in T_keep])
+    j_ptrs = (fp * n)(*[f(j) for j in j_keep])
+    c_keep = [c32(c) if len(c) else np.zeros((1, 4), dtype=F) for c in clouds]
+    c_ptrs = (fp * n)(*[f(c) for c in c_keep])
+    counts = (C.c_int32 * n)(*[len(c) for c in clouds])
+    p_keep = [np.ascontiguousarray(p, dtype=np.int32) for p in potentials]
+    p_ptrs = (ip * n)(*[i(p) for p in p_keep])
+    from dart_amd.tracker_no_obs import priors_array
+    arr = priors_array(priors, OrcContactPrior)
+    return models, T_keep, j_keep, T_ptrs, j_ptrs, c_ptrs, counts, p_ptrs, arr, (c_keep, p_keep)
+
+
+def optimize_poses_noobs(oms, T_mcs, joints, opts_struct, clouds, potentials, priors):
+    """orc_optimize_poses_noobs. opts_struct: NoObsOptions layout. Returns (T_mcs list, joints list, energy, iter_info, first)."""
+    models, T_keep, j_keep, T_ptrs, j_ptrs, c_ptrs, counts, p_ptrs, arr, keep = _noobs_args(oms, T_mcs, joints, clouds, potentials, priors)
+    D = sum(o.dims for o in oms)
+    info = np.zeros((max(opts_struct.numIterations, 1), 8), dtype=F)
+    first = np.zeros(D * D + D, dtype=F)
+    o = OrcNoObsOptions.from_buffer_copy(bytes(opts_struct))
+    lib().orc_optimize_poses_noobs.restype = C.c_float
+    e = lib().orc_optimize_poses_noobs(models, T_ptrs, j_ptrs, C.byref(o), c_ptrs, counts, p_ptrs, arr, len(priors), f(info), f(first))
+    return T_keep, [j_keep[m][:oms[m].n_joints] for m in range(len(oms))], float(e), info, first
+
+
+def get_error_noobs(oms, T_mcs, joints, opts_struct, clouds, potentials, priors):
+    models, T_keep, j_keep, T_ptrs, j_ptrs, c_ptrs, counts, p_ptrs, arr, keep = _noobs_args(oms, T_mcs, joints, clouds, potentials, priors)
+    o = OrcNoObsOptions.from_buffer_copy(bytes(opts_struct))
+    lib().orc_get_error_noobs.restype = C.c_float
+    return float(lib().orc_get_error_noobs(models, T_ptrs, j_ptrs, C.byref(o), c_ptrs, counts, p_ptrs, arr, len(priors)))
