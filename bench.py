@@ -1,22 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of BASELINE.json: Gauss-Newton iterations/s on one 640x480 Allegro frame
-(config 2: obs->mod + mod->obs), synthetic depth generated on device.
+(config 2: obs->mod + mod->obs, synthetic depth generated on device) + batched ContactGrasp refinement (config 4).
 
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one Optimizer::optimizePose call = observation-SDF build + opts.numIterations (5, the reference default)
-Gauss-Newton iterations starting from the same perturbed pose; `value` = GN iterations/s over the whole job. The
-path does not split one frame across GPUs (north_star): with N ranks every rank tracks its own frame (independent
-units, weak scaling) and a single RCCL all-gather collects {energy, pose} per frame at the end.
+Headline (`metric`/`value`): a "step" is one Optimizer::optimizePose call = observation-SDF build + opts.numIterations
+(5, the reference default) Gauss-Newton iterations from the same perturbed pose; `value` = GN iterations/s over the
+whole job. One frame is never split across GPUs (north_star): with N ranks every rank tracks its own frame
+(independent units, weak scaling) and one RCCL all-gather collects {energy, pose} per frame at the end.
 
-Extra objects on the JSON line:
-  roofline      dominant kernel's ALGORITHMIC bytes per launch / its average launch duration, measured with HIP events
-                on the launch stream in a second pass over the same K steps (events add overhead, so the throughput
-                pass runs without them); peak = 8 TB/s HBM (MI355X_MICROARCH.md). traffic = PMC HBM bytes (null here;
-                collected with rocprofv3 --pmc, see profiles/).
-  cpu_baseline  the CPU oracle (plain C restatement, "port") timed on this host on a bounded sample: whole steps of
-                the same workload, single thread.
+Extra objects on the same JSON line:
+  roofline        the dominant kernel of the headline path: ALGORITHMIC bytes per launch / its average launch duration,
+                  measured with HIP events on the launch stream in a second pass over the same K steps (events add
+                  overhead, so the throughput pass runs without them); peak = 8 TB/s HBM (MI355X_MICROARCH.md);
+                  `traffic` = PMC HBM bytes per launch when profiles/ holds them for this kernel, else null.
+  cpu_baseline    the CPU oracle (plain C restatement, "port") timed on this host on a bounded sample, 1 thread.
+  batched_grasps  BASELINE config 4: 4096 HumanHand grasp candidates x 40 iterations of OptimizerNoObs (contact priors
+                  + intersection terms), candidates sharded round-robin over the N ranks (strong scaling for this leg),
+                  one all-gather of {energy, pose}; grasps/s, its own roofline and CPU baseline.
 """
 import argparse
 import ctypes as C
@@ -32,7 +34,53 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0
-PROF_NAMES = ["obs_sdf_build", "raycast_prediction", "fused_assoc_obs2mod", "ne_mod2obs", "ne_self_intersection", "gn_solve", "refine", "other"]
+PROF_NAMES = ["obs_sdf_build", "raycast_trace_kernel", "fused_obs2mod_kernel", "ne_mod2obs_kernel", "ne_self_intersection_kernel",
+              "gn_solve_single_kernel", "raycast_replay_kernel", "valid_pixel_compaction", "gn_reduce_kernel", "noobs_terms_kernel",
+              "noobs_solve_kernel", "unused"]
+O_ASSOC, O_ASSOC_GRAD, O_NE_O2M, O_RAYCAST, O_M2O, O_INTER, O_PRIOR = 1, 2, 3, 4, 5, 6, 7
+N_CLASSES = 12
+# PMC HBM traffic per launch (bytes) measured with rocprofv3 --pmc, corrected as MI355X_MICROARCH.md prescribes; filled in
+# from profiles/ (see profiles/README.md). None = not collected for that kernel.
+PMC_TRAFFIC = {}
+_pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+if os.path.exists(_pmc_path):
+    with open(_pmc_path) as _f:
+        PMC_TRAFFIC = json.load(_f)
+
+
+def prof_collect(lib, fptr, iptr, check, fn, reps):
+    check(lib.dartk_profile_begin())
+    for _ in range(reps):
+        fn()
+    ms = np.zeros(N_CLASSES, dtype=np.float32)
+    cnt = np.zeros(N_CLASSES, dtype=np.int32)
+    check(lib.dartk_profile_end(fptr(ms), iptr(cnt)))
+    per_launch_us = {PROF_NAMES[i]: float(1000.0 * ms[i] / cnt[i]) for i in range(N_CLASSES) if cnt[i]}
+    per_step_us = {PROF_NAMES[i]: float(1000.0 * ms[i] / reps) for i in range(N_CLASSES) if cnt[i]}
+    return per_launch_us, per_step_us
+
+
+def tr_slab_floats(tr):
+    """floats of partial systems one candidate writes per terms-kernel launch (for the algorithmic-bytes figure)."""
+    D_ = sum(m.dims for m in tr.models)
+
+    def S(d):
+        return d + d * (d + 1) // 2 + 1
+    total = 0
+    many = tr.max_batch >= 64
+    n = len(tr.models)
+    lam = tr.opts.lambdaIntersection
+    for m in range(n):
+        tiles = (tr.clouds[m].shape[0] + 127) // 128
+        blocks = min(tiles, 4) if many else tiles
+        if lam[m + m * n] > 0 and tr.models[m].dims > 6:
+            total += blocks * S(tr.models[m].dims - 6)
+        for d in range(n):
+            if d != m and lam[m + d * n] > 0:
+                total += blocks * S(tr.models[m].dims)
+    tiles = (len(tr.priors) + 127) // 128
+    total += (min(tiles, 4) if many else tiles) * S(D_)
+    return total
 
 
 def main():
@@ -43,11 +91,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--norm-threshold", type=float, default=None, help="override the workload's normal gate (reference default -0.1)")
+    ap.add_argument("--grasp-candidates", type=int, default=4096)
+    ap.add_argument("--grasp-steps", type=int, default=3)
+    ap.add_argument("--no-grasps", action="store_true")
+    ap.add_argument("--no-tracking", action="store_true", help="profiling aid: skip the headline leg's timed loop")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from dart_amd import configs, device as D
+    from dart_amd import configs, device as D, sharding
     from dart_amd._abi import check, lib, fptr, iptr
     from dart_amd.optimizer import Optimizer, synthetic_observation
 
@@ -63,7 +115,20 @@ def main():
     D.init(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    # ---- workload: BASELINE config 2, one frame per rank (rank r perturbs the seed so frames differ)
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if not distributed:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ================================================================== headline: BASELINE config 2, one frame per rank
     sc = configs.config2()
     if args.norm_threshold is not None:
         sc.opts.normThreshold = args.norm_threshold
@@ -81,26 +146,17 @@ def main():
         dm.set_pose(sc.init_T_mc, sc.init_joints)
         opt.optimizePose(dm, vert, norm, sc.opts, debug=debug)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    n_steps = 0 if args.no_tracking else args.steps
+    for _ in range(0 if args.no_tracking else args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(n_steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
-    # ---- result gather (the path's only exchange): {energy, T_mc[12], joints} per frame
+    # result gather (the path's only exchange): {energy, T_mc[12], joints} per frame
     step(debug=True)
     T_mc, _, _, joints = dm.get_transforms()
     info = opt.iter_info.cpu().numpy()
@@ -109,59 +165,56 @@ def main():
         out = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(out, rec)
 
-    # ---- roofline leg (rank 0): per-kernel durations from HIP events over the same K steps
     roofline = None
     cpu_baseline = None
-    if rank == 0:
-        check(lib().dartk_profile_begin())
-        for _ in range(args.steps):
-            step()
-        ms = np.zeros(8, dtype=np.float32)
-        cnt = np.zeros(8, dtype=np.int32)
-        check(lib().dartk_profile_end(fptr(ms), iptr(cnt)))
-        per_launch_us = {PROF_NAMES[i]: (1000.0 * ms[i] / cnt[i] if cnt[i] else 0.0) for i in range(8)}
-        per_step_us = {PROF_NAMES[i]: 1000.0 * ms[i] / args.steps for i in range(8)}
-        dom = int(np.argmax(ms))
-
-        # algorithmic bytes (SURVEY 8d) from exact counts of one step of the CPU oracle on this workload
+    if rank == 0 and not args.no_tracking:
         import oracle_lib as O
+        per_launch_us, per_step_us = prof_collect(lib(), fptr, iptr, check, step, args.steps)
+        # algorithmic bytes (SURVEY 8d) from exact counts of one step of the CPU oracle on this workload
         om = O.OModel(sc.host_model, 0, sc.obs_layout)
         o_struct = sc.opts.c_struct(0, opt.pred_width, opt.pred_height, opt.pred_fl)
         v_np, n_np = vert.cpu().numpy(), norm.cpu().numpy()
         O.lib().orc_stats_reset()
         O.lib().orc_stats_enable(1)
-        tc0 = time.perf_counter()
         _, _, o_info, _ = O.optimize_pose(om, sc.init_T_mc, sc.init_joints, v_np, n_np, o_struct)
-        cpu_one = time.perf_counter() - tc0
         O.lib().orc_stats_enable(0)
         st = (C.c_longlong * 8)()
         O.lib().orc_stats_get(st)
-        A = sc.width * sc.height
         P = opt.pred_width * opt.pred_height
         S = 22 + 22 * 23 // 2 + 1
+        n_valid = int((v_np[..., 3] > 0).sum())
         n_assoc = float(o_info[:, 3].mean())
         n_pred = float(o_info[:, 4].mean())
+        n_sdfs = len(sc.host_model.sdfs)
         bytes_per_launch = {
-            # 16 B vertex per pixel + 32 B per trilinear lookup of the association scan + (16 B normal + 192 B gradient)
-            # per associated candidate + one partial system per workgroup
-            "fused_assoc_obs2mod": 16.0 * A + 32.0 * st[O_ASSOC] / iters + (16.0 + 32.0) * st[O_ASSOC_GRAD] / 6 / iters * 1.0
-                                   + 32.0 * st[O_ASSOC_GRAD] / iters + 4.0 * S * 256,
-            # 32 B per marching-step lookup + 16 B prediction write per pixel
-            "raycast_prediction": 32.0 * st[O_RAYCAST] / iters + 16.0 * P,
+            # 4 B index + 16 B vertex per valid pixel + 32 B per trilinear lookup of the association scan + (16 B normal +
+            # 192 B gradient) per associated candidate + one partial system per workgroup
+            "fused_obs2mod_kernel": 20.0 * n_valid + 32.0 * st[O_ASSOC] / iters + 16.0 * st[O_ASSOC_GRAD] / 6 / iters
+                                    + 32.0 * st[O_ASSOC_GRAD] / iters + 4.0 * S * ((n_valid + 127) // 128),
+            # 32 B per marching-step lookup (the reference's pruned count) + 8 B trace record per (pixel, SDF)
+            "raycast_trace_kernel": 32.0 * st[O_RAYCAST] / iters + 8.0 * P * n_sdfs,
+            "raycast_replay_kernel": 8.0 * P * n_sdfs + 32.0 * P,
             # 16 B per prediction pixel + 32 B per lookup (value + gradient) + partial systems
-            "ne_mod2obs": 16.0 * P + 32.0 * st[O_M2O] / iters + 4.0 * S * 256,
-            "gn_solve": 4.0 * S * 256 * 2,
+            "ne_mod2obs_kernel": 16.0 * P + 32.0 * st[O_M2O] / iters + 4.0 * S * 256,
+            "gn_reduce_kernel": 4.0 * S * (256 + (n_valid + 127) // 128) + 8.0 * S,
+            "gn_solve_single_kernel": 4.0 * 2 * S + 96.0 * 17 * 2,
             "obs_sdf_build": 4.0 * 64 ** 3 * 9 + 16.0 * 64 ** 3,
         }
-        name = PROF_NAMES[dom]
-        ach = bytes_per_launch.get(name, 0.0) / (per_launch_us[name] * 1e-6) / 1e9 if per_launch_us[name] else 0.0
+        cands = {k: v for k, v in per_step_us.items() if k in bytes_per_launch}
+        name = max(cands, key=cands.get)
+        ach = bytes_per_launch[name] / (per_launch_us[name] * 1e-6) / 1e9
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
-                    "algorithmic_bytes_per_launch": round(bytes_per_launch.get(name, 0.0)),
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": PMC_TRAFFIC.get(name),
+                    "algorithmic_bytes_per_launch": round(bytes_per_launch[name]),
                     "avg_launch_us": round(per_launch_us[name], 2),
-                    "per_step_us": {k: round(v, 2) for k, v in per_step_us.items() if v},
-                    "counts": {"associated_per_iter": n_assoc, "predicted_per_iter": n_pred,
-                               "assoc_lookups_per_iter": st[O_ASSOC] / iters, "raycast_lookups_per_iter": st[O_RAYCAST] / iters}}
+                    "per_step_us": {k: round(v, 2) for k, v in per_step_us.items()},
+                    "per_kernel_achieved_GBs": {k: round(bytes_per_launch[k] / (per_launch_us[k] * 1e-6) / 1e9, 2)
+                                                for k in bytes_per_launch if k in per_launch_us},
+                    "counts": {"valid_pixels": n_valid, "associated_per_iter": n_assoc, "predicted_per_iter": n_pred,
+                               "assoc_lookups_per_iter": st[O_ASSOC] / iters, "raycast_lookups_per_iter": st[O_RAYCAST] / iters},
+                    "note": "latency-bound at batch 1: one frame's working set (~35 MB/iteration, SDFs L2/MALL-resident) cannot "
+                            "approach the HBM roof; the obs->mod chain and the ray-cast + mod->obs chain overlap on two streams, "
+                            "so per_step_us sums exceed ms_per_step"}
         if not args.no_cpu_baseline:
             tc0 = time.perf_counter()
             for _ in range(args.cpu_steps):
@@ -171,24 +224,104 @@ def main():
                             "sample": "%d whole steps (obs-SDF build + %d iterations) of the same 640x480 Allegro workload, CPU oracle, 1 thread"
                                       % (args.cpu_steps, iters)}
 
+    # ================================================================== BASELINE config 4: batched ContactGrasp refinement
+    grasps = None
+    if not args.no_grasps:
+        n_cand = args.grasp_candidates
+        gs = configs.contact_grasp_scene(n_cand)
+        idx = sharding.shard_indices(n_cand, rank, world)
+        tr = configs.make_grasp_tracker(gs, max_batch=len(idx))
+        T_all, j_all = configs.grasp_batch_arrays(gs)
+        Td = torch.from_numpy(T_all[idx]).to(dev)
+        jd = torch.from_numpy(j_all[idx]).to(dev)
+        g_iters = gs.num_iterations
+
+        def grefine():
+            return tr.optimizePosesBatch(Td, jd, device_arrays=True)
+
+        def gstep():
+            T_o, j_o, e_o, _, _ = grefine()
+            poses = torch.cat([T_o.reshape(len(idx), -1), j_o], dim=1)
+            return sharding.gather_candidates(n_cand, rank, world, e_o, poses)     # RCCL all-gather of {energy, pose}
+
+        gstep()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.grasp_steps):
+            full_e, full_p = gstep()
+        barrier()
+        g_elapsed = max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            import oracle_lib as O
+            best = sharding.best_candidates(full_e, 5)
+            per_launch_us, per_step_us = prof_collect(lib(), fptr, iptr, check, grefine, 1)
+            # algorithmic bytes of one terms-kernel launch (contact priors + intersection) from oracle counts on a
+            # sample of this rank's candidates at their initial poses
+            oms = [O.OModel(gs.hand, 0), O.OModel(gs.obj, 1)]
+            o = tr._options_struct()
+            clouds = [c.cpu().numpy() for c in tr.clouds]
+            pots = [p.cpu().numpy() for p in tr.potentials]
+            sample = list(range(0, len(idx), max(1, len(idx) // 8)))[:8]
+            O.lib().orc_stats_reset()
+            O.lib().orc_stats_enable(1)
+            for c in sample:
+                O.get_error_noobs(oms, [T_all[idx[c], 0], T_all[idx[c], 1]], [j_all[idx[c]], np.zeros(0, dtype=np.float32)], o, clouds, pots, gs.priors)
+            O.lib().orc_stats_enable(0)
+            st = (C.c_longlong * 8)()
+            O.lib().orc_stats_get(st)
+            lookups = (st[O_INTER] + st[O_PRIOR]) / len(sample)
+            Q = len(gs.priors)
+            Cn = sum(len(c) for c in clouds) + len(clouds[0])      # the hand cloud is walked twice (self + object)
+            per_cand = 24.0 * Q + 16.0 * Cn + 32.0 * lookups + 4.0 * tr_slab_floats(tr)
+            bpl = per_cand * len(idx)
+            us = per_launch_us["noobs_terms_kernel"]
+            ach = bpl / (us * 1e-6) / 1e9
+            g_cpu = None
+            if not args.no_cpu_baseline:
+                o2 = tr._options_struct()
+                o2.numIterations = 10
+                tc0 = time.perf_counter()
+                n_cpu = 0
+                while time.perf_counter() - tc0 < 10.0 and n_cpu < 64:
+                    c = idx[n_cpu % len(idx)]
+                    O.optimize_poses_noobs(oms, [T_all[c, 0], T_all[c, 1]], [j_all[c], np.zeros(0, dtype=np.float32)], o2, clouds, pots, gs.priors)
+                    n_cpu += 1
+                cpu_t = time.perf_counter() - tc0
+                g_cpu = {"value": round(n_cpu * 10 / g_iters / cpu_t, 4), "unit": "grasps/s", "cores": 1, "kind": "port",
+                         "sample": "%d candidates x 10 of the %d iterations (+ getError), CPU oracle, 1 thread, scaled to %d iterations"
+                                   % (n_cpu, g_iters, g_iters)}
+            grasps = {"metric": "batched ContactGrasp refinement", "value": round(n_cand * args.grasp_steps / g_elapsed, 2), "unit": "grasps/s",
+                      "gn_iterations_per_s": round(n_cand * args.grasp_steps * g_iters / g_elapsed, 1),
+                      "scaling": "strong", "n_candidates": n_cand, "candidates_per_gpu": len(idx), "iterations": g_iters,
+                      "steps": args.grasp_steps, "ms_per_step": round(1000.0 * g_elapsed / args.grasp_steps, 3),
+                      "config": {"workload": "BASELINE configs[3]: %d HumanHand (26 DOF, 16 SDFs, proxy geometry) + ellipsoid object candidates, "
+                                             "%d contact priors (500 attract / 2000 repulse / thumb), hand self- and hand<->object "
+                                             "intersection, %d iterations + getError, round-robin over %d GPU(s), one all-gather of "
+                                             "{energy, pose}" % (n_cand, Q, g_iters, world)},
+                      "best_candidates": [int(b) for b in best],
+                      "roofline": {"bound": "hbm", "kernel": "noobs_terms_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": PMC_TRAFFIC.get("noobs_terms_kernel"),
+                                   "algorithmic_bytes_per_launch": round(bpl), "avg_launch_us": round(us, 2),
+                                   "per_step_us": {k: round(v, 2) for k, v in per_step_us.items()},
+                                   "lookups_per_candidate_per_iteration": lookups},
+                      "cpu_baseline": g_cpu}
+
     if rank == 0:
-        value = world * args.steps * iters / elapsed
+        value = world * n_steps * iters / elapsed if n_steps else 0.0
         line = {
             "metric": "Gauss-Newton iters/sec (640x480 Allegro)", "value": round(value, 2), "unit": "GN iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / max(n_steps, 1), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: Allegro 22-DOF (17 SDFs, proxy geometry), synthetic 640x480 depth, "
                                    "prediction 320x240, 64^3 obs SDF, obs->mod + mod->obs, %d GN iterations per optimizePose call, "
                                    "normThreshold %.1f; one frame per GPU" % (iters, sc.opts.normThreshold),
                        "iterations_per_step": iters, "frames_per_gpu": 1, "parallelism": "independent frames, 1 per GPU"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "batched_grasps": grasps,
         }
         print(json.dumps(line, default=float))
     if distributed:
         dist.destroy_process_group()
 
-
-O_ASSOC, O_ASSOC_GRAD, O_NE_O2M, O_RAYCAST, O_M2O = 1, 2, 3, 4, 5
 
 if __name__ == "__main__":
     main()

@@ -20,18 +20,15 @@ static constexpr int GN_MAX_BLOCKS = 256;     // one partial system per CU at mo
 struct ProfEvent { int cls; hipEvent_t a, b; };
 static bool g_prof_on = false;
 static std::vector<ProfEvent> g_prof;
-struct ProfScope {
-    hipStream_t st; int idx;
-    ProfScope(int cls, hipStream_t s) : st(s), idx(-1) {
-        if (!g_prof_on) return;
-        ProfEvent e; e.cls = cls;
-        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
-        (void)hipEventRecord(e.a, st);
-        g_prof.push_back(e);
-        idx = (int)g_prof.size() - 1;
-    }
-    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, st); }
-};
+int prof_push(int cls, hipStream_t st) {
+    if (!g_prof_on) return -1;
+    ProfEvent e; e.cls = cls;
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return -1;
+    (void)hipEventRecord(e.a, st);
+    g_prof.push_back(e);
+    return (int)g_prof.size() - 1;
+}
+void prof_pop(int idx, hipStream_t st) { (void)hipEventRecord(g_prof[idx].b, st); }
 
 // -----------------------------------------------------------------------------------------------------
 // Fused association + obs->mod normal equations (obsToMod.cu:12-114 + :246-337). The reference materialises a
@@ -574,7 +571,6 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         }
         if (useB) {
             {
-                ProfScope ps(DARTK_PROF_RAYCAST, stB);
                 rc = gn_launch_raycast(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2),
                                        o->predWidth, o->predHeight, 0, m, d_prediction, stB);
                 if (rc) return rc;
@@ -623,9 +619,12 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         a.regularization = o->regularization; a.lmLambda = o->regularizationScaled;
         a.iterInfo = d_iterInfo ? d_iterInfo + 8 * it : nullptr;
         a.firstSystem = (it == 0) ? d_firstSystem : nullptr;
+        if (nTerms) {
+            ProfScope ps(DARTK_PROF_REDUCE, st);
+            hipLaunchKernelGGL(gn_reduce_kernel, dim3((S + 63) / 64, nTerms), dim3(256), 0, st, ra);
+        }
         {
             ProfScope ps(DARTK_PROF_SOLVE, st);
-            if (nTerms) hipLaunchKernelGGL(gn_reduce_kernel, dim3((S + 63) / 64, nTerms), dim3(256), 0, st, ra);
             hipLaunchKernelGGL(gn_solve_single_kernel, dim3(1), dim3(64), ldsS, st, m, a);
         }
         DARTK_HIP(hipGetLastError());

@@ -24,6 +24,15 @@ int gn_launch_ne_mod2obs(const float *d_pred, int width, int height, const Model
 int gn_launch_ne_self(const float *d_sites, int nSites, const ModelView &m, const int *d_pot, float *slabs, int nBlocks,
                       hipStream_t st);
 
+// optional per-kernel-class timing with HIP events on the launch stream (dartk_profile_begin / _end)
+int prof_push(int cls, hipStream_t st);       // returns an event-pair index or -1 when profiling is off
+void prof_pop(int idx, hipStream_t st);
+struct ProfScope {
+    hipStream_t st; int idx;
+    ProfScope(int cls, hipStream_t s) : st(s), idx(prof_push(cls, s)) {}
+    ~ProfScope() { if (idx >= 0) prof_pop(idx, st); }
+};
+
 #ifdef __HIPCC__
 
 struct AssocResult {

@@ -156,8 +156,12 @@ static int launch_raycast(float flx, float fly, float ppx, float ppy, int width,
     if (rc) return rc;
     const long long tasks = (long long)((width + 7) / 8) * ((height + 7) / 8) * m.nSdfs;
     DARTK_REQUIRE(tasks < (1ll << 31), "ray-cast of %dx%d against %d SDFs exceeds the launch limits", width, height, m.nSdfs);
-    hipLaunchKernelGGL(raycast_trace_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height, m,
-                       (float2 *)ws->rayBuf, levelSet);
+    {
+        ProfScope ps(DARTK_PROF_RAYCAST, st);
+        hipLaunchKernelGGL(raycast_trace_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height, m,
+                           (float2 *)ws->rayBuf, levelSet);
+    }
+    ProfScope ps2(DARTK_PROF_RAYCAST_REPLAY, st);
     hipLaunchKernelGGL(raycast_replay_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height,
                        modelNum, m, (const float2 *)ws->rayBuf, (float4 *)d_prediction);
     DARTK_HIP(hipGetLastError());

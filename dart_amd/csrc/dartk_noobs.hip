@@ -575,6 +575,7 @@ int dartk_noobs_set_priors(dartk_noobs_t h, const dartk_contact_prior *h_priors,
 static int noobs_launch_terms(NoObs *t, int batch, hipStream_t st) {
     const dim3 grid(t->totalBlocks, batch), block(NE_BLOCK);
     if (t->totalBlocks == 0) return DARTK_OK;
+    ProfScope ps(DARTK_PROF_NOOBS_TERMS, st);
 #define DARTK_LAUNCH_TERMS(PPT_)                                                                                 \
     do {                                                                                                         \
         auto kfn = noobs_terms_kernel<PPT_>;                                                                     \
@@ -625,6 +626,7 @@ int dartk_noobs_optimize_poses(dartk_noobs_t h, const dartk_noobs_options *o, in
         rc = noobs_launch_terms(t, batch, st);
         if (rc) return rc;
         a.iteration = it; a.energyOnly = 0;
+        ProfScope ps(DARTK_PROF_NOOBS_SOLVE, st);
         hipLaunchKernelGGL(noobs_solve_kernel, dim3(batch), dim3(64), t->ldsSolve, st, t->d, t->poses, t->slabs, a);
     }
     // getError at the final poses (optimizer.cpp:980-982)

@@ -270,8 +270,9 @@ int dartk_noobs_get_error(dartk_noobs_t t, const dartk_noobs_options *opts, int 
  * around every launch between dartk_profile_begin() and dartk_profile_end(). Used by bench.py's roofline leg;
  * adds two event records per launch, so throughput is timed with profiling off. */
 enum dartk_prof_class {
-    DARTK_PROF_OBS_SDF = 0, DARTK_PROF_RAYCAST = 1, DARTK_PROF_FUSED_OBS2MOD = 2, DARTK_PROF_NE_MOD2OBS = 3,
-    DARTK_PROF_NE_SELF = 4, DARTK_PROF_SOLVE = 5, DARTK_PROF_REFINE = 6, DARTK_PROF_OTHER = 7, DARTK_PROF_CLASSES = 8
+    DARTK_PROF_OBS_SDF = 0, DARTK_PROF_RAYCAST = 1 /* trace kernel */, DARTK_PROF_FUSED_OBS2MOD = 2, DARTK_PROF_NE_MOD2OBS = 3,
+    DARTK_PROF_NE_SELF = 4, DARTK_PROF_SOLVE = 5, DARTK_PROF_RAYCAST_REPLAY = 6, DARTK_PROF_OTHER = 7, DARTK_PROF_REDUCE = 8,
+    DARTK_PROF_NOOBS_TERMS = 9, DARTK_PROF_NOOBS_SOLVE = 10, DARTK_PROF_CLASSES = 12
 };
 int dartk_profile_begin(void);
 int dartk_profile_end(float *h_ms_total /*[DARTK_PROF_CLASSES]*/, int32_t *h_launches /*[DARTK_PROF_CLASSES]*/);

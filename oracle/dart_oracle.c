@@ -766,6 +766,7 @@ float orc_error_mod2obs(const float *pred, int width, int height, const orc_grid
 int orc_ne_self_intersection(const float *sites, int nSites, const orc_model *m, const float *T_fm,
                              const float *T_mf, const int32_t *pot, int reduction, int redDims,
                              const float *dtheta_dalpha, const int32_t *mapping, float *result) {
+    const int oldcat_ = stat_enter(ORC_STAT_INTERSECTION);
     const int fullDims = 6 + m->n_joints;
     const int adims = (reduction ? redDims : fullDims) - 6;
     sys_acc s = sys_new(adims);
@@ -802,6 +803,7 @@ int orc_ne_self_intersection(const float *sites, int nSites, const orc_model *m,
     }
     free(de);
     sys_emit(&s, result);
+    stat_enter(oldcat_);
     return nColl;
 }
 
@@ -809,6 +811,7 @@ int orc_ne_intersection(const float *sites, int nSites, const float *T_ds, const
                         const orc_model *src, const float *T_fm_src, const float *T_mf_src,
                         const orc_model *dst, const float *T_fm_dst, const float *T_mf_dst, int reduction,
                         int redDims, const float *dtheta_dalpha, const int32_t *mapping, float *result) {
+    const int oldcat_ = stat_enter(ORC_STAT_INTERSECTION);
     const int fullDims = 6 + src->n_joints;
     const int dims = reduction ? redDims : fullDims;
     sys_acc s = sys_new(dims);
@@ -846,6 +849,7 @@ int orc_ne_intersection(const float *sites, int nSites, const float *T_ds, const
     }
     free(de);
     sys_emit(&s, result);
+    stat_enter(oldcat_);
     return nColl;
 }
 
@@ -960,12 +964,30 @@ void orc_solve_upper(const float *A, const float *b, int n, float *x) {
 /* ------------------------------------------------------------------------------------------------
  * contact prior (contact_prior.cpp:8-205)
  * ---------------------------------------------------------------------------------------------- */
+static float contact_prior_contribution_(const orc_contact_prior *p, const orc_model *const *models,
+                                         const float *const *T_mcs, const float *const *T_cms,
+                                         const float *const *T_fms, const float *const *T_mfs,
+                                         const int32_t *modelOffsets, const int32_t *modelDims,
+                                         int priorParamOffset, float *JTJ, int sys, float *JTe,
+                                         int32_t *dstSdfOut);
 float orc_contact_prior_contribution(const orc_contact_prior *p, const orc_model *const *models,
                                      const float *const *T_mcs, const float *const *T_cms,
                                      const float *const *T_fms, const float *const *T_mfs,
                                      const int32_t *modelOffsets, const int32_t *modelDims,
                                      int priorParamOffset, float *JTJ, int sys, float *JTe,
                                      int32_t *dstSdfOut) {
+    const int oldcat = stat_enter(ORC_STAT_PRIOR);
+    const float e = contact_prior_contribution_(p, models, T_mcs, T_cms, T_fms, T_mfs, modelOffsets, modelDims, priorParamOffset,
+                                                JTJ, sys, JTe, dstSdfOut);
+    stat_enter(oldcat);
+    return e;
+}
+static float contact_prior_contribution_(const orc_contact_prior *p, const orc_model *const *models,
+                                         const float *const *T_mcs, const float *const *T_cms,
+                                         const float *const *T_fms, const float *const *T_mfs,
+                                         const int32_t *modelOffsets, const int32_t *modelDims,
+                                         int priorParamOffset, float *JTJ, int sys, float *JTe,
+                                         int32_t *dstSdfOut) {
     const int sign = p->invert ? -1 : 1;
     float error = sign * p->weight * p->contactThreshold;
     if (dstSdfOut) *dstSdfOut = -1;
