@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as gfx950's TCC slots
+require). Units and corrections per MI355X_MICROARCH.md "HBM": counter values are KiB; on gfx950 FETCH_SIZE reports one
+half of the bytes of wide coalesced reads, so the read side is doubled (an upper bound for the 4-byte gathers that dominate
+these kernels: access widths other than 16 B/lane are uncalibrated). Output: table + profiles/pmc_traffic.json
+(bytes per launch = 2*FETCH + WRITE)."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    tot = defaultdict(float)
+    disp = defaultdict(set)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"]
+            tot[k] += float(r["Counter_Value"])
+            disp[k].add(r["Dispatch_Id"])
+    return {k: (tot[k] / max(len(disp[k]), 1), len(disp[k])) for k in tot}
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "").replace("dartk::", "")
+    return n.split("<")[0]
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    print("%-40s %8s %16s %16s %18s" % ("kernel", "launches", "FETCH_KiB/launch", "WRITE_KiB/launch", "HBM_bytes/launch"))
+    for k in sorted(fetch, key=lambda k: -fetch[k][0] * fetch[k][1]):
+        f, n = fetch[k]
+        w = write.get(k, (0.0, 0))[0]
+        b = (2.0 * f + w) * 1024.0
+        print("%-40s %8d %16.1f %16.1f %18.0f" % (short(k)[:40], n, f, w, b))
+        if "dartk::" in k:
+            out[short(k)] = round(b)
+    if len(sys.argv) > 3:
+        json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
