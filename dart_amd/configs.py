@@ -243,3 +243,71 @@ def grasp_batch_arrays(sc):
     T[:, 0] = sc.init_T_mc
     T[:, 1] = se3.identity()
     return T, sc.init_joints.copy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: Barrett hand (8 joints reduced to 4, grasp_analyzer.cpp:393-420) + object, multi-model tracking with
+# observations, self-intersection 5 and hand<->object intersection 100, 1280x720 depth.
+# ---------------------------------------------------------------------------------------------------------------------
+@dataclass
+class MultiScene:
+    name: str
+    hand: object
+    obj: object
+    reduction: object
+    potential: np.ndarray
+    width: int
+    height: int
+    fl: tuple
+    pp: tuple
+    true: list          # [(T_mc, reduced articulation)] per model
+    init: list
+    num_iterations: int
+
+
+def barrett_reduction(hand):
+    from .pose import LinearPoseReduction
+    Fd, R = 8, 4
+    A = np.zeros(Fd * R, dtype=F)
+    for f, r in ((0, 0), (1, 1), (2, 1), (3, 0), (4, 2), (5, 2), (6, 3), (7, 3)):
+        A[f * R + r] = 1
+    lim = np.asarray(hand.joint_limits, dtype=F).reshape(-1, 2)
+    # LinearPoseReduction::init copies the first redDims entries of the FULL joint limits (pose.cpp:58-64)
+    return LinearPoseReduction(Fd, R, A, np.zeros(Fd, dtype=F), lim[:R, 0], lim[:R, 1], hand.joint_names[:R])
+
+
+def config5(width=1280, height=720, frame=0):
+    rng = np.random.default_rng(SEED + 5 + frame)
+    hand = load_asset("barrett").voxelize(0.005, 0.10)
+    obj = _object_model()
+    pot, _ = _hand_potential("barrett", len(hand.sdfs))
+    red = barrett_reduction(hand)
+    s = width / 640.0
+    fl = (FOCAL * s, FOCAL * s)
+    art = np.array([0.3, 0.9, 0.8, 1.0], dtype=F) * (0.8 + 0.4 * rng.random(4)).astype(F)
+    art = np.clip(art, [red.getMin(i) for i in range(4)], [red.getMax(i) for i in range(4)]).astype(F)
+    T_cm_h = se3.mul(se3.translation(-0.05, 0.02, 0.55), se3.exp(np.array([0, 0, 0, 1.3, 0.3, -0.2], dtype=F)))
+    T_cm_o = se3.mul(se3.translation(0.12, -0.02, 0.60), se3.exp(np.array([0, 0, 0, 0.2, 0.5, 0.1], dtype=F)))
+    true = [(se3.invert(T_cm_h), art), (se3.invert(T_cm_o), np.zeros(0, dtype=F))]
+    init = []
+    for T_mc, a in true:
+        lim = np.stack([[red.getMin(i), red.getMax(i)] for i in range(len(a))]) if len(a) else None
+        T, j = _perturb(T_mc, a.astype(np.float64), lim, rng, 0.012, 3.0, 0.08)
+        init.append((T, j))
+    return MultiScene("C5-barrett-object", hand, obj, red, pot, width, height, fl, (width / 2, height / 2), true, init, 5)
+
+
+def make_multi_tracker(sc):
+    from .tracker import Tracker
+    tr = Tracker(sc.width, sc.height, sc.fl[0])
+    h = tr.addModel(sc.hand, reduction=sc.reduction, cloud_seed=21)
+    tr.setIntersectionPotentialMatrix(h, sc.potential)
+    ob = tr.addModel(sc.obj, cloud_seed=22)
+    o = tr.getOptions()
+    n = 2
+    o.numIterations = sc.num_iterations
+    o.focalLength = float(sc.fl[0])
+    o.lambdaIntersection[h + n * h] = 5.0
+    o.lambdaIntersection[ob + n * h] = 100.0
+    o.lambdaIntersection[h + n * ob] = 100.0
+    return tr

@@ -1,0 +1,196 @@
+"""dart::Tracker + Optimizer::optimizePoses (src/tracker.{h,cpp}, src/optimization/optimizer.cpp:524-781) -- host mirror
+of the multi-model tracking loop with observations and (optionally) reduced poses.
+
+Round-1 form: the loop is driven from the host exactly as the reference drives it -- every term is one C-ABI call into
+libdartk (association, normal equations, intersection, ray-cast, obs-SDF), the packed systems come back with one copy
+per term, assembly / the triangular solve / the pose update run here in fp32 numpy following optimizer.cpp line by
+line. (The single-model and the NoObs loops are device-resident; this one is next)"""
+import numpy as np
+import torch
+
+from . import device, se3
+from .optimizer import OptimizationOptions
+from .pose import NullReduction, Pose
+
+F = np.float32
+
+
+def unpack(eJ, JTJ, sys_, mult, dims):
+    """Optimizer::unpack (optimizer.cpp:50-70): eJ += mult*J^T e; upper JTJ(i,j) += mult*packed[j(j+1)/2+i]; returns mult*e."""
+    m = F(mult)
+    eJ += m * sys_[:dims]
+    packed = sys_[dims:dims + dims * (dims + 1) // 2]
+    for j in range(dims):
+        base = (j * (j + 1)) >> 1
+        JTJ[:j + 1, j] += m * packed[base:base + j + 1]
+    return F(m * sys_[dims + dims * (dims + 1) // 2])
+
+
+def solve_upper(U, b):
+    """Eigen SparseMatrix::triangularView<Upper>().solve (optimizer.cpp:732): back substitution, columns last to first, a
+    column is skipped when its rhs entry is exactly 0 (SURVEY A-1)."""
+    n = len(b)
+    x = b.astype(F).copy()
+    for i in range(n - 1, -1, -1):
+        t = x[i]
+        if t != 0:
+            x[i] = F(t / U[i, i])
+            t = x[i]
+            col = U[:i, i]
+            nz = col != 0
+            x[:i][nz] = (x[:i][nz] - t * col[nz]).astype(F)
+    return x
+
+
+class Tracker:
+    """Tracker (tracker.h:25-130): models, poses (with reductions), collision clouds, potential matrices, options."""
+
+    def __init__(self, depth_width, depth_height, focal_length, pred_width=None, pred_height=None):
+        self.width, self.height = depth_width, depth_height
+        self.fl = (F(focal_length), F(focal_length)) if np.isscalar(focal_length) else tuple(F(v) for v in focal_length)
+        self.pred_width = depth_width // 2 if pred_width is None else pred_width       # tracker.cpp:280
+        self.pred_height = depth_height // 2 if pred_height is None else pred_height
+        self.pred_fl = (F(F(self.fl[0] * F(self.pred_width)) / F(depth_width)), F(F(self.fl[1] * F(self.pred_width)) / F(depth_width)))
+        self.models, self.host_models, self.poses, self.clouds, self.potentials = [], [], [], [], []
+        self.red_dev = []     # per model: None | ("linear", A tensor, redDims) | ("map", mapping tensor, redDims)
+        self.opts = OptimizationOptions()
+        self.opts.lambdaIntersection = []
+        self.opts.regularization, self.opts.regularizationScaled = [], []
+        self.opts.distThreshold, self.opts.planeOffset, self.opts.planeNormal = [], [], []
+        self.priors = []
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.prediction = torch.zeros((self.pred_height, self.pred_width, 4), dtype=torch.float32, device=dev)
+        self.iteration_summaries = None
+        self.first_system = None
+
+    def addModel(self, host_model, reduction=None, collision_cloud_density=1e5, cloud_seed=0):
+        """Tracker::addModel (tracker.cpp:59-267): device mirror incl. the 64^3 observation SDF, collision cloud, pose."""
+        m_id = len(self.models)
+        dev = self.prediction.device
+        self.models.append(device.DeviceModel(host_model, model_id=m_id, obs_layout=host_model.obs_sdf_layout()))
+        self.host_models.append(host_model)
+        lim = np.asarray(host_model.joint_limits, dtype=F).reshape(-1, 2)
+        red = reduction or NullReduction(host_model.n_joints, lim[:, 0], lim[:, 1], host_model.joint_names)
+        self.poses.append(Pose(red))
+        rd = 6 + red.getReducedDimensions()
+        if red.isNull():
+            self.red_dev.append(None)
+        elif red.isParamMap():
+            self.red_dev.append(("map", torch.from_numpy(np.ascontiguousarray(red.getMapping(), dtype=np.int32)).to(dev), rd))
+        else:
+            self.red_dev.append(("linear", torch.from_numpy(np.ascontiguousarray(red.getFirstDerivatives(), dtype=F)).to(dev), rd))
+        cloud = host_model.collision_cloud(collision_cloud_density, seed=cloud_seed)
+        self.clouds.append(torch.from_numpy(np.ascontiguousarray(cloud, dtype=F)).to(dev))
+        n_s = len(host_model.sdfs)
+        self.potentials.append(torch.ones(n_s * n_s, dtype=torch.int32, device=dev))
+        n = len(self.models)
+        old = self.opts.lambdaIntersection
+        lam = [0.0] * (n * n)
+        for s in range(n - 1):
+            for d in range(n - 1):
+                lam[s + d * n] = old[s + d * (n - 1)]
+        self.opts.lambdaIntersection = lam
+        self.opts.regularization.append(self.opts.regularization[0] if self.opts.regularization else 1e-20)
+        self.opts.regularizationScaled.append(self.opts.regularizationScaled[0] if self.opts.regularizationScaled else 1.0)
+        self.opts.distThreshold.append(self.opts.distThreshold[0] if self.opts.distThreshold else 0.03)
+        self.opts.planeOffset.append(-0.03)
+        self.opts.planeNormal.append((0.0, 0.0, 0.0))
+        return m_id
+
+    def getNumModels(self):
+        return len(self.models)
+
+    def getOptions(self):
+        return self.opts
+
+    def getPose(self, m):
+        return self.poses[m]
+
+    def setIntersectionPotentialMatrix(self, m, matrix):
+        self.potentials[m] = torch.from_numpy(np.ascontiguousarray(matrix, dtype=np.int32).reshape(-1)).to(self.prediction.device)
+
+    def updatePose(self, m):
+        """Tracker::updatePose: projectReducedToFull + MirroredModel::setPose."""
+        p = self.poses[m]
+        p.projectReducedToFull()
+        self.models[m].set_pose(p.getTransformCameraToModel(), p.getArticulation())
+
+    # ---- Optimizer::optimizePoses (optimizer.cpp:524-781)
+    def optimizePoses(self, vert, norm, debug=False):
+        if self.priors:
+            raise NotImplementedError("priors in the observation loop are not wired up yet (device priors live in TrackerNoObs)")
+        o = self.opts
+        n = len(self.models)
+        models, poses = self.models, self.poses
+        rdims = [p.getReducedDimensions() for p in poses]
+        offs = np.concatenate([[0], np.cumsum(rdims)]).astype(int)
+        D = int(offs[-1])
+        info = np.zeros((max(o.numIterations, 1), n, 8), dtype=F)
+        T_obs = []
+        if o.lambdaModToObs > 0:                                  # generateObsSdf per model, :574-580
+            for m in range(n):
+                self.updatePose(m)
+                device.generate_obs_sdf(vert, models[m], o.focalLength)
+                T_obs.append(poses[m].getTransformCameraToModel().copy())
+        for it in range(o.numIterations):
+            U = np.zeros((D, D), dtype=F)
+            JTe = np.zeros(D, dtype=F)
+            for m in range(n):
+                self.updatePose(m)
+            if o.lambdaModToObs > 0:                              # raytracePrediction + cullUnobservable, :610-618
+                device.raycast_prediction(models, self.pred_fl, (F(self.pred_width // 2), F(self.pred_height // 2)), self.pred_width,
+                                          self.pred_height, prediction=self.prediction)
+                device.cull_unobservable(self.prediction, vert)
+            pts, counts, _ = device.error_and_data_association_multi(vert, norm, models, o.distThreshold[:n], o.planeOffset[:n],
+                                                                     o.planeNormal[:n], pts_list=getattr(self, "_pts", None))
+            self._pts = pts
+            for m in range(n):
+                dims, off, red = rdims[m], offs[m], self.red_dev[m]
+                eJ = np.zeros(dims, dtype=F)
+                J = np.zeros((dims, dims), dtype=F)
+                eO2M = eM2O = eInt = F(0)
+                n_pred = 0
+                if o.lambdaObsToMod > 0:
+                    s_ = device.norm_eqns_obs_to_mod(vert, models[m], pts[m], int(counts[m]), o.huberDelta, reduction=red).cpu().numpy()
+                    eO2M = unpack(eJ, J, s_, o.lambdaObsToMod, dims)
+                if o.lambdaModToObs > 0:
+                    # reduced wrappers use the model's current T_mc, the full one T_obsSdf_c (modToObs.cu:851-988 vs :713-780)
+                    s_d, cnt = device.norm_eqns_mod_to_obs(self.prediction, models[m], T_gc=T_obs[m], reduction=red)
+                    eM2O = unpack(eJ, J, s_d.cpu().numpy(), o.lambdaModToObs, dims)
+                    n_pred = int(cnt.item())
+                lam_self = o.lambdaIntersection[m + m * n]
+                if lam_self > 0 and dims > 6:
+                    s_ = device.norm_eqns_self_intersection(self.clouds[m], models[m], self.potentials[m], reduction=red).cpu().numpy()
+                    ad = dims - 6
+                    eJt, Jt = np.zeros(ad, dtype=F), np.zeros((ad, ad), dtype=F)
+                    eInt = unpack(eJt, Jt, s_, lam_self, ad)
+                    eJ[6:] += eJt
+                    J[6:, 6:] += Jt
+                for d in range(n):
+                    lam = o.lambdaIntersection[m + d * n]
+                    if d == m or not lam > 0:
+                        continue
+                    T_ds = se3.mul(poses[d].getTransformCameraToModel(), poses[m].getTransformModelToCamera())
+                    T_sd = se3.invert(T_ds)
+                    s_ = device.norm_eqns_intersection(self.clouds[m], models[m], models[d], T_ds, T_sd, reduction=red).cpu().numpy()
+                    eInt = unpack(eJ, J, s_, lam, dims)
+                J = np.triu(J) + np.triu(J, 1).T                                   # make JTJ symmetric, :688-692
+                J[np.diag_indices(dims)] += F(o.regularization[m]) * F(1.0)        # :695
+                J[np.diag_indices(dims)] += F(o.regularizationScaled[m]) * J[np.diag_indices(dims)]     # :698-700
+                U[off:off + dims, off:off + dims] = np.triu(J)                     # :707-713 (damping matrices are zero)
+                JTe[off:off + dims] = eJ
+                info[it, m] = (eO2M, eM2O, eInt, counts[m], n_pred, 0, 0, 0)
+            if it == 0 and debug:
+                self.first_system = np.concatenate([U.reshape(-1), JTe])
+            x = (-solve_upper(U, JTe)).astype(F)                                   # :732
+            for m in range(n):                                                     # :734-755
+                p, off = poses[m], offs[m]
+                dT = se3.exp(x[off:off + 6])
+                p.setTransformCameraToModel(se3.mul(dT, p.getTransformCameraToModel()))
+                ra = p.getReducedArticulation()
+                for i in range(p.getReducedArticulatedDimensions()):
+                    lo, hi = (p.getReducedMin(i), p.getReducedMax(i))
+                    ra[i] = min(max(F(lo), F(ra[i] + x[off + 6 + i])), F(hi))
+                self.updatePose(m)
+        self.iteration_summaries = info
+        return -1.0

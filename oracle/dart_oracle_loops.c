@@ -271,3 +271,163 @@ float orc_optimize_poses_noobs(const orc_model *const *models, float *const *T_m
     noobs_free(&c);
     return orc_get_error_noobs(models, T_mcs, joints, o, clouds, nClouds, potentials, priors, nPriors);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer::optimizePoses (optimizer.cpp:524-781)
+ * ---------------------------------------------------------------------------------------------- */
+static void project_reduced(const orc_model *m, const orc_reduction *r, const float *art, float *full) {
+    const int nf = m->n_joints;
+    if (!r || r->type == 0) { for (int f = 0; f < nf; ++f) full[f] = art[f]; return; }
+    if (r->type == 2) { for (int f = 0; f < nf; ++f) full[f] = art[r->mapping[f]]; return; }   /* pose.cpp:91-97 */
+    for (int f = 0; f < nf; ++f) {                                                              /* pose.cpp:66-73 */
+        full[f] = r->b[f];
+        for (int k = 0; k < r->redArt; ++k) full[f] += art[k] * r->A[k + f * r->redArt];
+    }
+}
+
+void orc_optimize_poses(const orc_model *const *models, float *const *T_mcs, float *const *art, const orc_reduction *red,
+                        const orc_multi_options *o, const float *vert, const float *norm, int width, int height,
+                        const float *const *clouds, const int32_t *nClouds, const int32_t *const *potentials,
+                        const orc_contact_prior *priors, int nPriors, float *const *obsSdf, float *iterInfo,
+                        float *firstSystem) {
+    const int n = o->nModels;
+    int offs[ORC_MAX_MODELS], rdims[ORC_MAX_MODELS], D = 0;
+    float *T_mf[ORC_MAX_MODELS], *T_fm[ORC_MAX_MODELS], *T_cm[ORC_MAX_MODELS], *full[ORC_MAX_MODELS], *T_obs[ORC_MAX_MODELS];
+    orc_da_point *pts[ORC_MAX_MODELS];
+    orc_grid obs[ORC_MAX_MODELS];
+    const float *cT_mc[ORC_MAX_MODELS], *cT_cm[ORC_MAX_MODELS], *cT_fm[ORC_MAX_MODELS], *cT_mf[ORC_MAX_MODELS];
+    int maxDims = 0;
+    for (int m = 0; m < n; ++m) {
+        const int redType = red ? red[m].type : 0;
+        rdims[m] = 6 + (redType ? red[m].redArt : models[m]->n_joints);
+        offs[m] = D; D += rdims[m];
+        if (6 + models[m]->n_joints > maxDims) maxDims = 6 + models[m]->n_joints;
+        T_mf[m] = (float *)malloc(sizeof(float) * 12 * (size_t)models[m]->n_frames);
+        T_fm[m] = (float *)malloc(sizeof(float) * 12 * (size_t)models[m]->n_frames);
+        T_cm[m] = (float *)malloc(sizeof(float) * 12);
+        T_obs[m] = (float *)malloc(sizeof(float) * 12);
+        full[m] = (float *)calloc((size_t)models[m]->n_joints + 1, sizeof(float));
+        pts[m] = (orc_da_point *)malloc(sizeof(orc_da_point) * (size_t)width * height);
+        obs[m].dim[0] = models[m]->obs_sdf_dim[0]; obs[m].dim[1] = models[m]->obs_sdf_dim[1]; obs[m].dim[2] = models[m]->obs_sdf_dim[2];
+        obs[m].offset[0] = models[m]->obs_sdf_offset[0]; obs[m].offset[1] = models[m]->obs_sdf_offset[1]; obs[m].offset[2] = models[m]->obs_sdf_offset[2];
+        obs[m].resolution = models[m]->obs_sdf_resolution;
+        obs[m].data = obsSdf ? obsSdf[m] : NULL;
+    }
+    const int sysN = D + 3;          /* frozen contact points share one all-zero parameter slot (see noobs_init) */
+    float *JTJ = (float *)malloc(sizeof(float) * (size_t)sysN * sysN);
+    float *JTe = (float *)malloc(sizeof(float) * (size_t)sysN);
+    float *x = (float *)malloc(sizeof(float) * (size_t)sysN);
+    float *sys = (float *)malloc(sizeof(float) * (size_t)sys_len(maxDims));
+    float *pred = (float *)calloc((size_t)o->predWidth * o->predHeight * 4, sizeof(float));
+    float *T_mc_flat = (float *)malloc(sizeof(float) * 12 * (size_t)n);
+
+    if (o->lambdaModToObs > 0) { /* generateObsSdf per model with its start pose, optimizer.cpp:574-580 */
+        for (int m = 0; m < n; ++m) {
+            const size_t nv = (size_t)obs[m].dim[0] * obs[m].dim[1] * obs[m].dim[2];
+            float *tmp = (float *)malloc(sizeof(float) * nv);
+            orc_se3_invert(T_mcs[m], T_cm[m]);
+            orc_splat_obs_sdf(vert, width, height, T_cm[m], &obs[m], o->focalLength, obsSdf[m]);
+            orc_distance_transform_3d(obsSdf[m], tmp, obs[m].dim[0], obs[m].dim[1], obs[m].dim[2], 1);
+            memcpy(obsSdf[m], tmp, sizeof(float) * nv);
+            free(tmp);
+            memcpy(T_obs[m], T_mcs[m], sizeof(float) * 12);
+        }
+    }
+    for (int it = 0; it < o->numIterations; ++it) {
+        memset(JTJ, 0, sizeof(float) * (size_t)sysN * sysN);
+        memset(JTe, 0, sizeof(float) * (size_t)sysN);
+        for (int m = 0; m < n; ++m) { /* projectReducedToFull; setPose */
+            project_reduced(models[m], red ? &red[m] : NULL, art[m], full[m]);
+            orc_fk_set_pose(models[m], full[m], T_mf[m], T_fm[m]);
+            orc_se3_invert(T_mcs[m], T_cm[m]);
+            memcpy(T_mc_flat + 12 * m, T_mcs[m], sizeof(float) * 12);
+            cT_mc[m] = T_mcs[m]; cT_cm[m] = T_cm[m]; cT_fm[m] = T_fm[m]; cT_mf[m] = T_mf[m];
+        }
+        if (o->lambdaModToObs > 0) { /* raytracePrediction (one pass per model) + cullUnobservable, :610-618 */
+            for (int m = 0; m < n; ++m)
+                orc_raycast_prediction(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2), o->predWidth,
+                                       o->predHeight, m, models[m], T_mcs[m], T_fm[m], T_mf[m], 0.0f, pred);
+            orc_cull_unobservable(pred, o->predWidth, o->predHeight, vert, width, height);
+        }
+        int32_t counts[ORC_MAX_MODELS];
+        float pn[ORC_MAX_MODELS * 3];
+        for (int m = 0; m < n; ++m) { pn[3 * m] = o->planeNormal[m][0]; pn[3 * m + 1] = o->planeNormal[m][1]; pn[3 * m + 2] = o->planeNormal[m][2]; }
+        orc_assoc_multi(vert, norm, width, height, n, models, T_mc_flat, (const float *const *)T_fm, o->distThreshold, o->planeOffset, pn,
+                        pts, counts, NULL, NULL);
+        for (int m = 0; m < n; ++m) {
+            const int dims = rdims[m], off = offs[m], fullDims = 6 + models[m]->n_joints;
+            const int redType = red ? red[m].type : 0;
+            const float *A = redType == 1 ? red[m].A : NULL;
+            const int32_t *map = redType == 2 ? red[m].mapping : NULL;
+            float *eJ = (float *)calloc((size_t)dims, sizeof(float));
+            float *J = (float *)calloc((size_t)dims * dims, sizeof(float));
+            float eO2M = 0, eM2O = 0, eInt = 0;
+            int nPred = 0;
+            if (o->lambdaObsToMod > 0) {
+                orc_ne_obs2mod(vert, models[m], T_mcs[m], T_fm[m], T_mf[m], pts[m], counts[m], o->huberDelta, redType, dims, A, map, sys);
+                eO2M = orc_unpack(eJ, J, dims, sys, o->lambdaObsToMod, dims);
+            }
+            if (o->lambdaModToObs > 0) { /* reduced wrappers use the model's CURRENT T_mc, the full one T_obsSdf_c (modToObs.cu:851-988) */
+                nPred = orc_ne_mod2obs(pred, o->predWidth, o->predHeight, m, models[m], redType ? T_mcs[m] : T_obs[m], T_fm[m], T_mf[m], &obs[m],
+                                       -1.0f, redType, dims, A, map, sys);
+                eM2O = orc_unpack(eJ, J, dims, sys, o->lambdaModToObs, dims);
+            }
+            if (o->lambdaIntersection[m + m * n] > 0 && dims > 6) {
+                const int ad = dims - 6;
+                orc_ne_self_intersection(clouds[m], nClouds[m], models[m], T_fm[m], T_mf[m], potentials[m], redType, dims, A, map, sys);
+                float *eJt = (float *)calloc((size_t)ad, sizeof(float));
+                float *Jt = (float *)calloc((size_t)ad * ad, sizeof(float));
+                eInt = orc_unpack(eJt, Jt, ad, sys, o->lambdaIntersection[m + m * n], ad);
+                for (int i = 0; i < ad; ++i) {
+                    eJ[6 + i] += eJt[i];
+                    for (int j = 0; j < ad; ++j) J[(6 + i) * dims + 6 + j] += Jt[i * ad + j];
+                }
+                free(eJt); free(Jt);
+            }
+            for (int d = 0; d < n; ++d) {
+                if (d == m || !(o->lambdaIntersection[m + d * n] > 0)) continue;
+                float T_ds[12], T_sd[12];
+                orc_se3_mul(T_mcs[d], T_cm[m], T_ds);
+                orc_se3_invert(T_ds, T_sd);
+                orc_ne_intersection(clouds[m], nClouds[m], T_ds, T_sd, models[m], T_fm[m], T_mf[m], models[d], T_fm[d], T_mf[d], redType, dims,
+                                    A, map, sys);
+                eInt = orc_unpack(eJ, J, dims, sys, o->lambdaIntersection[m + d * n], dims);
+            }
+            (void)fullDims;
+            /* symmetrise; += reg*I; A_ii += lm*A_ii; += damping (zero); scatter the upper triangle (:688-714) */
+            for (int i = 0; i < dims; ++i) for (int j = 0; j < i; ++j) J[i * dims + j] = J[j * dims + i];
+            for (int i = 0; i < dims; ++i) J[i * dims + i] += o->regularization[m] * 1.0f;
+            for (int i = 0; i < dims; ++i) J[i * dims + i] += o->regularizationScaled[m] * J[i * dims + i];
+            for (int i = 0; i < dims; ++i) for (int j = i; j < dims; ++j)
+                if (J[i * dims + j] != 0) JTJ[(off + i) * sysN + off + j] = J[i * dims + j];
+            for (int i = 0; i < dims; ++i) JTe[off + i] = eJ[i];
+            if (iterInfo) {
+                float *r = iterInfo + ((size_t)it * n + m) * 8;
+                r[0] = eO2M; r[1] = eM2O; r[2] = eInt; r[3] = (float)counts[m]; r[4] = (float)nPred; r[5] = r[6] = r[7] = 0;
+            }
+            free(eJ); free(J);
+        }
+        for (int p = 0; p < nPriors; ++p) /* :727-730 */
+            orc_contact_prior_contribution(&priors[p], models, cT_mc, cT_cm, cT_fm, cT_mf, offs, rdims, D, JTJ, sysN, JTe, NULL);
+        if (it == 0 && firstSystem) {
+            for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) firstSystem[i * D + j] = JTJ[i * sysN + j];
+            for (int i = 0; i < D; ++i) firstSystem[D * D + i] = JTe[i];
+        }
+        orc_solve_upper(JTJ, JTe, sysN, x);
+        for (int i = 0; i < sysN; ++i) x[i] = -x[i];
+        for (int m = 0; m < n; ++m) { /* :734-755 */
+            float dT[12];
+            orc_se3_exp(x + offs[m], dT);
+            orc_se3_mul(dT, T_mcs[m], T_mcs[m]);
+            const int redType = red ? red[m].type : 0;
+            const int na = rdims[m] - 6;
+            for (int i = 0; i < na; ++i) {
+                const float lo = redType ? red[m].mins[i] : models[m]->joint_limits[2 * i];
+                const float hi = redType ? red[m].maxs[i] : models[m]->joint_limits[2 * i + 1];
+                art[m][i] = fminf(fmaxf(lo, art[m][i] + x[offs[m] + 6 + i]), hi);
+            }
+        }
+    }
+    for (int m = 0; m < n; ++m) { free(T_mf[m]); free(T_fm[m]); free(T_cm[m]); free(T_obs[m]); free(full[m]); free(pts[m]); }
+    free(JTJ); free(JTe); free(x); free(sys); free(pred); free(T_mc_flat);
+}

@@ -26,6 +26,37 @@ void orc_optimize_pose(const orc_model *m, float *T_mc, float *joints, const flo
                        int width, int height, const orc_opt_options *o, const float *cloud, int nCloud,
                        const int32_t *potential, float *obsSdfData, float *iterInfo, float *firstSystem);
 
+/* ---- Optimizer::optimizePoses (multi-model tracking with observations) ---- */
+typedef struct {
+    int32_t type;            /* 0 NullReduction, 1 LinearPoseReduction, 2 ParamMapPoseReduction (pose_reduction.h) */
+    int32_t redArt;          /* reduced articulated dimensions */
+    const float *A;          /* [redArt * fullArt], A[r + f*redArt] (pose.cpp:66-73) = the device dtheta_dalpha */
+    const float *b;          /* [fullArt] */
+    const int32_t *mapping;  /* [fullArt] (type 2) */
+    const float *mins, *maxs;/* [redArt] reduced limits */
+} orc_reduction;
+
+typedef struct {
+    int32_t numIterations, nModels;
+    float distThreshold[8], planeOffset[8], planeNormal[8][3];
+    float regularization[8], regularizationScaled[8];
+    float lambdaObsToMod, lambdaModToObs;
+    float lambdaIntersection[64];
+    float huberDelta, focalLength;
+    int32_t predWidth, predHeight;
+    float predFl[2];
+} orc_multi_options;
+
+/* Optimizer::optimizePoses (optimizer.cpp:524-781), zero damping matrices. T_mcs[m] and art[m] (the REDUCED articulation
+ * of model m; the full one for NullReduction) are updated in place. obsSdf[m]: scratch of model m's obs-SDF size.
+ * iterInfo (optional): [iteration][model][8] = {errObsToMod, errModToObs, errIntersection (last term), nAssociated,
+ * nPredicted, 0,0,0}. firstSystem (optional): dense upper JTJ [D*D] + JTe [D] of iteration 0 right before the solve. */
+void orc_optimize_poses(const orc_model *const *models, float *const *T_mcs, float *const *art, const orc_reduction *red,
+                        const orc_multi_options *o, const float *vert, const float *norm, int width, int height,
+                        const float *const *clouds, const int32_t *nClouds, const int32_t *const *potentials,
+                        const orc_contact_prior *priors, int nPriors, float *const *obsSdf, float *iterInfo,
+                        float *firstSystem);
+
 /* ---- OptimizerNoObs (ContactGrasp refinement) ---- */
 #define ORC_MAX_MODELS 8
 typedef struct {

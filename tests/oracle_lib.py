@@ -329,3 +329,77 @@ def get_error_noobs(oms, T_mcs, joints, opts_struct, clouds, potentials, priors)
     o = OrcNoObsOptions.from_buffer_copy(bytes(opts_struct))
     lib().orc_get_error_noobs.restype = C.c_float
     return float(lib().orc_get_error_noobs(models, T_ptrs, j_ptrs, C.byref(o), c_ptrs, counts, p_ptrs, arr, len(priors)))
+
+
+# ---------------------------------------------------------------------------------------------- Optimizer::optimizePoses
+class OrcReduction(C.Structure):
+    _fields_ = [("type", C.c_int32), ("redArt", C.c_int32), ("A", fp), ("b", fp), ("mapping", ip), ("mins", fp), ("maxs", fp)]
+
+
+class OrcMultiOptions(C.Structure):
+    _fields_ = [("numIterations", C.c_int32), ("nModels", C.c_int32), ("distThreshold", C.c_float * 8), ("planeOffset", C.c_float * 8),
+                ("planeNormal", (C.c_float * 3) * 8), ("regularization", C.c_float * 8), ("regularizationScaled", C.c_float * 8),
+                ("lambdaObsToMod", C.c_float), ("lambdaModToObs", C.c_float), ("lambdaIntersection", C.c_float * 64),
+                ("huberDelta", C.c_float), ("focalLength", C.c_float), ("predWidth", C.c_int32), ("predHeight", C.c_int32),
+                ("predFl", C.c_float * 2)]
+
+
+def optimize_poses(tracker, vert, norm, T_mcs, arts):
+    """orc_optimize_poses on the state of a dart_amd.tracker.Tracker (models, reductions, clouds, options).
+    Returns (T_mcs, reduced articulations, iter_info [it, model, 8], first_system)."""
+    n = len(tracker.models)
+    oms = [OModel(tracker.host_models[m], m, tracker.models[m].obs_layout) for m in range(n)]
+    models = (C.POINTER(OrcModel) * n)(*[C.pointer(o.desc) for o in oms])
+    o = tracker.opts
+    mo = OrcMultiOptions()
+    mo.numIterations, mo.nModels = int(o.numIterations), n
+    for m in range(n):
+        mo.distThreshold[m] = o.distThreshold[m]
+        mo.planeOffset[m] = o.planeOffset[m]
+        for k in range(3):
+            mo.planeNormal[m][k] = o.planeNormal[m][k]
+        mo.regularization[m] = o.regularization[m]
+        mo.regularizationScaled[m] = o.regularizationScaled[m]
+    for k in range(n * n):
+        mo.lambdaIntersection[k] = o.lambdaIntersection[k]
+    mo.lambdaObsToMod, mo.lambdaModToObs = o.lambdaObsToMod, o.lambdaModToObs
+    mo.huberDelta, mo.focalLength = o.huberDelta, o.focalLength
+    mo.predWidth, mo.predHeight = tracker.pred_width, tracker.pred_height
+    mo.predFl[0], mo.predFl[1] = float(tracker.pred_fl[0]), float(tracker.pred_fl[1])
+    reds = (OrcReduction * n)()
+    keep = []
+    for m in range(n):
+        r = tracker.poses[m].getReduction()
+        if r.isNull():
+            reds[m].type, reds[m].redArt = 0, tracker.host_models[m].n_joints
+            continue
+        A, b = c32(r.getFirstDerivatives()), c32(r._b)
+        mins = c32([r.getMin(k) for k in range(r.getReducedDimensions())])
+        maxs = c32([r.getMax(k) for k in range(r.getReducedDimensions())])
+        keep += [A, b, mins, maxs]
+        reds[m].type = 2 if r.isParamMap() else 1
+        reds[m].redArt = r.getReducedDimensions()
+        reds[m].A, reds[m].b, reds[m].mins, reds[m].maxs = f(A), f(b), f(mins), f(maxs)
+        if r.isParamMap():
+            mp = np.ascontiguousarray(r.getMapping(), dtype=np.int32)
+            keep.append(mp)
+            reds[m].mapping = i(mp)
+    T_keep = [c32(T_mcs[m]).copy() for m in range(n)]
+    a_keep = [np.concatenate([c32(arts[m]), np.zeros(1, dtype=F)]) for m in range(n)]
+    T_ptrs = (fp * n)(*[f(t) for t in T_keep])
+    a_ptrs = (fp * n)(*[f(a) for a in a_keep])
+    clouds = [c.cpu().numpy() for c in tracker.clouds]
+    c_keep = [c32(c) if len(c) else np.zeros((1, 4), dtype=F) for c in clouds]
+    c_ptrs = (fp * n)(*[f(c) for c in c_keep])
+    counts = (C.c_int32 * n)(*[len(c) for c in clouds])
+    p_keep = [np.ascontiguousarray(p.cpu().numpy(), dtype=np.int32) for p in tracker.potentials]
+    p_ptrs = (ip * n)(*[i(p) for p in p_keep])
+    obs_keep = [np.zeros(int(np.prod(tracker.models[m].obs_layout[0])), dtype=F) for m in range(n)]
+    obs_ptrs = (fp * n)(*[f(x) for x in obs_keep])
+    D = sum(tracker.poses[m].getReducedDimensions() for m in range(n))
+    info = np.zeros((max(mo.numIterations, 1), n, 8), dtype=F)
+    first = np.zeros(D * D + D, dtype=F)
+    h, w = vert.shape[:2]
+    lib().orc_optimize_poses(models, T_ptrs, a_ptrs, reds, C.byref(mo), f(c32(vert)), f(c32(norm)), w, h, c_ptrs, counts, p_ptrs,
+                             None, 0, obs_ptrs, f(info), f(first))
+    return T_keep, [a_keep[m][:len(arts[m])] for m in range(n)], info, first

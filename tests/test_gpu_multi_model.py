@@ -1,0 +1,86 @@
+"""GPU parity: multi-model tracking with observations and a reduced pose (BASELINE config 5: Barrett 8->4 + object;
+Optimizer::optimizePoses, optimizer.cpp:524-781) vs the CPU oracle. Every term goes through the C ABI; the loop's host
+part (assembly, triangular solve, update) is dart_amd/tracker.py."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from dart_amd import configs
+from dart_amd.optimizer import synthetic_observation
+from test_gpu_optimize_pose import pose_diff
+
+F = np.float32
+pytestmark = pytest.mark.gpu
+
+
+def setup(width, height, iters, frame=0):
+    sc = configs.config5(width, height, frame)
+    tr = configs.make_multi_tracker(sc)
+    for m, (T, a) in enumerate(sc.true):
+        tr.getPose(m).setTransformCameraToModel(T)
+        tr.getPose(m).getReducedArticulation()[:] = a
+        tr.updatePose(m)
+    _, vert, norm = synthetic_observation(tr.models, sc.width, sc.height, sc.fl, sc.pp)
+    tr.getOptions().numIterations = iters
+    for m, (T, a) in enumerate(sc.init):
+        tr.getPose(m).setTransformCameraToModel(T)
+        tr.getPose(m).getReducedArticulation()[:] = a
+    return sc, tr, vert, norm
+
+
+def run(width, height, iters, frame=0):
+    sc, tr, vert, norm = setup(width, height, iters, frame)
+    tr.optimizePoses(vert, norm, debug=True)
+    oT, oa, oinfo, ofirst = O.optimize_poses(tr, vert.cpu().numpy(), norm.cpu().numpy(), [T for T, _ in sc.init], [a for _, a in sc.init])
+    return sc, tr, oT, oa, oinfo, ofirst
+
+
+def check(sc, tr, oT, oa, oinfo, ofirst, strict_iters):
+    ginfo = tr.iteration_summaries
+    # iteration 0: same association / prediction counts per model, same system
+    assert np.array_equal(ginfo[0, :, 3:5], oinfo[0, :, 3:5]), (ginfo[0], oinfo[0])
+    assert ginfo[0, 0, 3] > 200 and ginfo[0, 1, 3] > 100 and ginfo[0, 0, 4] > 50
+    D = 16
+    for sl in (slice(0, D * D), slice(D * D, D * D + D)):
+        nref = np.linalg.norm(ofirst[sl].astype(np.float64))
+        assert np.linalg.norm(tr.first_system[sl].astype(np.float64) - ofirst[sl]) / nref < 1e-4
+    flipped = np.any(ginfo[:, :, 3:5] != oinfo[:, :, 3:5], axis=(1, 2))
+    first_flip = int(np.argmax(flipped)) if flipped.any() else len(ginfo)
+    print("counts agree for %d of %d iterations" % (first_flip, len(ginfo)))
+    assert first_flip >= strict_iters
+    for m in range(2):
+        dt, dr = pose_diff(tr.getPose(m).getTransformCameraToModel(), oT[m])
+        da = float(np.abs(tr.getPose(m).getReducedArticulation() - oa[m]).max()) if len(oa[m]) else 0.0
+        raw = float(np.abs(tr.getPose(m).getTransformCameraToModel() - oT[m]).max())
+        moved = float(np.abs(oT[m] - sc.init[m][0]).max())
+        print("model %d: |dt|=%.2e m |dr|=%.2e rad max|dq_red|=%.2e (max|dT| %.2e, moved %.2e from the start)" % (m, dt, dr, da, raw, moved))
+        assert moved > 1e-4
+        if first_flip == len(ginfo):
+            assert dt < 1e-3 and dr < 1e-3 and da < 1e-3
+        else:
+            assert dt < 5e-3 and dr < 5e-2 and da < 5e-2
+
+
+def test_config5_small_matches_oracle(gpu):
+    check(*run(320, 180, 4), strict_iters=2)
+
+
+def test_config5_moves_towards_truth_and_respects_reduced_limits(gpu):
+    sc, tr, vert, norm = setup(320, 180, 5)
+    t0 = [pose_diff(sc.init[m][0], sc.true[m][0])[0] for m in range(2)]
+    tr.optimizePoses(vert, norm)
+    t1 = [pose_diff(tr.getPose(m).getTransformCameraToModel(), sc.true[m][0])[0] for m in range(2)]
+    print("translation error before %s after %s" % (t0, t1))
+    assert t1[0] < t0[0] and t1[1] < t0[1]
+    ra = tr.getPose(0).getReducedArticulation()
+    for i in range(4):
+        assert tr.getPose(0).getReducedMin(i) <= ra[i] <= tr.getPose(0).getReducedMax(i)
+    # coupled joints stay coupled (A maps reduced dof 1 to full joints 1 and 2, grasp_analyzer.cpp:411-412)
+    full = tr.getPose(0).getArticulation()
+    assert full[1] == full[2] and full[0] == full[3] and full[4] == full[5] and full[6] == full[7]
+
+
+def test_config5_full_resolution(gpu):
+    """BASELINE config 5 at its full 1280x720: counts and first system against the oracle, 2 iterations."""
+    check(*run(1280, 720, 2), strict_iters=1)
