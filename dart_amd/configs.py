@@ -193,6 +193,10 @@ def contact_grasp_scene(n_candidates=1, asset="human_hand", n_attract=500, n_rep
     rng.shuffle(contact)
     rng.shuffle(free)
     contact, free = contact[:n_attract], free[:n_repulse]
+    # the order of the priors only fixes the order of the sums; keep neighbours together (spatial.py)
+    from .spatial import morton_order
+    contact = contact[morton_order(surf[contact])]
+    free = free[morton_order(surf[free])]
     att_w, rep_w, thumb_w = 150.0, 20.0, 25.0      # after the GUI setters ran (undivided, grasp_analyzer.cpp:941-965)
     thr = 0.02
     priors = []

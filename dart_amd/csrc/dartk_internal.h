@@ -24,7 +24,18 @@ struct SdfDev {               // 64 bytes
     //   p > 2.50001  <=>  p >= lo25 ;   p < dim - 2.50001  <=>  p <= hi25{x,y,z}
     float lo25, hi25x, hi25y, hi25z;
     float lo05, hi05x, hi05y, hi05z;
+    // "keep boxes" in grid coordinates: a trilinear lookup at g reads voxels x0 = (int)(g.x-0.5) and x0+1 (same for y, z)
+    // and is a convex combination of them, so it can only be < 0 (box 0) or <= kNearThr[k-1] metres (boxes 1..3) if that
+    // 2x2x2 cell touches the bounding box of the voxels that are. Outside the box the lookup cannot change any decision
+    // of the association (threshold test), the intersection terms (r < 0) or the contact priors (|err| <= threshold), so
+    // it is skipped: identical results, far fewer gathers than the reference's padded grids imply (padding 10 cm).
+    float keepLo[4][3], keepHi[4][3];       // keep iff keepLo <= g < keepHi on every axis
 };
+static constexpr float kNearThr[3] = {0.02f, 0.03f, 0.05f};
+// box to use for a distance threshold (metres): the tightest one that still covers it; -1 = no pruning
+__host__ __device__ inline int keep_slot(float thr) {
+    return (thr <= kNearThr[0]) ? 1 : (thr <= kNearThr[1]) ? 2 : (thr <= kNearThr[2]) ? 3 : -1;
+}
 
 struct ModelView {
     int nFrames, nJoints, nSdfs, modelId;
@@ -56,6 +67,7 @@ struct Model {        // host-side handle (dartk_model_t)
     float *h_pin;     // pinned staging for pose uploads
     size_t obsVoxels;
     float *dtTmp;     // obs-SDF distance transform scratch (generateObsSdf)
+    bool uniformRes;  // all SDFs share one resolution
 };
 
 // ---- error handling -------------------------------------------------------------------------------
@@ -170,7 +182,13 @@ __device__ __forceinline__ bool in_bounds_grad_interp(const SdfDev &s, f3 g) {  
 __device__ __forceinline__ bool in_bounds_interp(const SdfDev &s, f3 g) {       // grid_3d.h:63-67
     return g.x >= s.lo05 && g.x <= s.hi05x && g.y >= s.lo05 && g.y <= s.hi05y && g.z >= s.lo05 && g.z <= s.hi05z;
 }
+__device__ __forceinline__ bool in_keep_box(const SdfDev &s, int slot, f3 g) {
+    if (slot < 0) return true;
+    return g.x >= s.keepLo[slot][0] && g.x < s.keepHi[slot][0] && g.y >= s.keepLo[slot][1] && g.y < s.keepHi[slot][1] &&
+           g.z >= s.keepLo[slot][2] && g.z < s.keepHi[slot][2];
+}
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return a + t * (b - a); }
+struct __attribute__((packed, aligned(4))) f2u { float a, b; };   // x-neighbours fetched with one 8-byte load
 
 // getValueInterpolated (grid_3d.h:86-112); data points at voxel (0,0,0) of the grid
 __device__ __forceinline__ float grid_value(const float *__restrict__ data, int dimx, int dimy, f3 g) {
@@ -179,10 +197,12 @@ __device__ __forceinline__ float grid_value(const float *__restrict__ data, int 
     const float fx = tx - (float)x0, fy = ty - (float)y0, fz = tz - (float)z0;
     const float *p = data + (x0 + dimx * (y0 + dimy * z0));
     const int sy = dimx, sz = dimx * dimy;
-    const float v000 = p[0], v100 = p[1];
-    const float v010 = p[sy], v110 = p[sy + 1];
-    const float v001 = p[sz], v101 = p[sz + 1];
-    const float v011 = p[sz + sy], v111 = p[sz + sy + 1];
+    const f2u q00 = *reinterpret_cast<const f2u *>(p), q10 = *reinterpret_cast<const f2u *>(p + sy);
+    const f2u q01 = *reinterpret_cast<const f2u *>(p + sz), q11 = *reinterpret_cast<const f2u *>(p + sz + sy);
+    const float v000 = q00.a, v100 = q00.b;
+    const float v010 = q10.a, v110 = q10.b;
+    const float v001 = q01.a, v101 = q01.b;
+    const float v011 = q11.a, v111 = q11.b;
     const float dx00 = lerpf(v000, v100, fx);
     const float dx01 = lerpf(v001, v101, fx);
     const float dx10 = lerpf(v010, v110, fx);

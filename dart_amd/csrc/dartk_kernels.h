@@ -56,12 +56,13 @@ __device__ __forceinline__ AssocResult associate_point(const ModelView &m, float
     float best = 1e20f;
     int grid = -1;
     const int nSdfs = m.nSdfs;
+    const int slot = keep_slot(distThr);     // SDFs that cannot come within the threshold cannot change the outcome
     for (int g = 0; g < nSdfs; ++g) {
         const int f = m.sdfFrame[g];
         const f3 xf = se3_apply_w(T_fm + 12 * f, r.xm.x, r.xm.y, r.xm.z, xc.w);
         const SdfDev &s = m.sdfs[g];
         const f3 xg = grid_coords(s, xf);
-        if (!in_bounds_grad_interp(s, xg)) continue;
+        if (!in_bounds_grad_interp(s, xg) || !in_keep_box(s, slot, xg)) continue;
         const float d = grid_value(m.grids + s.dataOff, s.dimx, s.dimy, xg) * s.res;
         if (d < best) { best = d; grid = g; }
     }
@@ -103,20 +104,49 @@ struct Collision {
     f3 vg;        // grid coordinates in the penetrated SDF
 };
 
+// ---- cheap conservative reject of (point, SDF) pairs ------------------------------------------------------------------
+// The exact path per pair is a frame transform, three IEEE divisions and a dozen bound tests before the first voxel is
+// read, yet nearly every pair is a point of one link against the SDF of a far-away link. Per workgroup and SDF, bounding
+// spheres (model frame, {cx, cy, cz, r^2}) of the keep boxes [0..3] and of the interpolation box [4] are put in LDS; a
+// point outside the sphere is outside the box for certain (radius grown by far more than the rounding of either path),
+// so the pair is dropped with 7 VALU operations and the decisions of the exact path are unchanged.
+static constexpr int kSphereSlots = 5;
+static constexpr int kSphereStride = 4 * kSphereSlots;     // floats per SDF
+__device__ __forceinline__ void make_spheres(const SdfDev &s, const float *T_mf_f, float *out) {
+    for (int k = 0; k < kSphereSlots; ++k) {
+        float lo[3], hi[3];
+        if (k < 4) { for (int a = 0; a < 3; ++a) { lo[a] = s.keepLo[k][a]; hi[a] = s.keepHi[k][a]; } }
+        else { lo[0] = lo[1] = lo[2] = s.lo05; hi[0] = s.hi05x; hi[1] = s.hi05y; hi[2] = s.hi05z; }
+        float *o = out + 4 * k;
+        if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) { o[0] = o[1] = o[2] = 0.0f; o[3] = -1.0f; continue; }   // empty box
+        const float cx = s.ox + s.res * 0.5f * (lo[0] + hi[0]), cy = s.oy + s.res * 0.5f * (lo[1] + hi[1]), cz = s.oz + s.res * 0.5f * (lo[2] + hi[2]);
+        const f3 c = se3_apply_w(T_mf_f, cx, cy, cz, 1.0f);
+        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        const float r = 0.5f * s.res * sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f + 1e-4f;
+        o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = r * r;
+    }
+}
+__device__ __forceinline__ bool sphere_reject(const float *sph, f3 p) {
+    const float dx = p.x - sph[0], dy = p.y - sph[1], dz = p.z - sph[2];
+    return dx * dx + dy * dy + dz * dz > sph[3];
+}
+
 // First penetrated destination SDF of a point given in the destination model's frame
-// (intersection.cu:100-142 / :405-441). pot == nullptr means "test every SDF" (inter-model case).
+// (intersection.cu:100-142 / :405-441). pot == nullptr means "test every SDF" (inter-model case); pot may point
+// to LDS or global memory. sph (optional): the destination model's spheres (make_spheres, LDS).
 __device__ __forceinline__ Collision first_collision(const ModelView &dst, const float *T_fm_dst, f3 v_dm,
-                                                     const int *__restrict__ pot, int srcGrid) {
+                                                     const int *pot, int srcGrid, const float *sph = nullptr) {
     Collision c;
     c.hit = false; c.dstGrid = -1; c.residual = 0.0f; c.vg.x = c.vg.y = c.vg.z = 0.0f;
     const int n = dst.nSdfs;
     for (int g = 0; g < n; ++g) {
         if (pot && !pot[g + srcGrid * n]) continue;
+        if (sph && sphere_reject(sph + kSphereStride * g, v_dm)) continue;
+        const SdfDev &s = dst.sdfs[g];
         const int f = dst.sdfFrame[g];
         const f3 vd = se3_apply_w(T_fm_dst + 12 * f, v_dm.x, v_dm.y, v_dm.z, 1.0f);
-        const SdfDev &s = dst.sdfs[g];
         const f3 vg = grid_coords(s, vd);
-        if (!in_bounds_grad_interp(s, vg)) continue;
+        if (!in_bounds_grad_interp(s, vg) || !in_keep_box(s, 0, vg)) continue;     // r < 0 needs a negative corner
         const float r = grid_value(dst.grids + s.dataOff, s.dimx, s.dimy, vg) * s.res;
         if (r < 0) { c.hit = true; c.dstGrid = g; c.residual = r; c.vg = vg; break; }
     }

@@ -184,6 +184,28 @@ static void fill_bounds(SdfDev &s) {
     s.hi05z = next_below((double)(unsigned)s.dimz - 0.50001);
 }
 
+// bounding boxes (grid coordinates) of the voxels with value < 0 and with value*res <= kNearThr[k]; see SdfDev
+static void fill_keep_boxes(SdfDev &s, const float *data) {
+    int lo[4][3], hi[4][3];
+    for (int k = 0; k < 4; ++k) for (int a = 0; a < 3; ++a) { lo[k][a] = 1 << 30; hi[k][a] = -1; }
+    for (int z = 0; z < s.dimz; ++z) for (int y = 0; y < s.dimy; ++y) {
+        const float *row = data + (size_t)s.dimx * (y + (size_t)s.dimy * z);
+        for (int x = 0; x < s.dimx; ++x) {
+            const float v = row[x];
+            // compared in metres as the kernels do (v*res)
+            const float d = v * s.res;
+            // small safety margins: an interpolated value may round a few ulp outside the range of its corners
+            const bool in[4] = {!(v >= 1e-4f), !(d > kNearThr[0] * 1.0001f), !(d > kNearThr[1] * 1.0001f), !(d > kNearThr[2] * 1.0001f)};
+            const int c[3] = {x, y, z};
+            for (int k = 0; k < 4; ++k) if (in[k]) for (int a = 0; a < 3; ++a) { if (c[a] < lo[k][a]) lo[k][a] = c[a]; if (c[a] > hi[k][a]) hi[k][a] = c[a]; }
+        }
+    }
+    for (int k = 0; k < 4; ++k) for (int a = 0; a < 3; ++a) {
+        if (hi[k][a] < 0) { s.keepLo[k][a] = 1e30f; s.keepHi[k][a] = -1e30f; }
+        else { s.keepLo[k][a] = (float)lo[k][a] - 0.5f; s.keepHi[k][a] = (float)hi[k][a] + 1.5f; }
+    }
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int dartk_model_create(const dartk_model_desc *d, dartk_model_t *out) {
@@ -237,6 +259,7 @@ int dartk_model_create(const dartk_model_desc *d, dartk_model_t *out) {
         g.res = d->sdf_resolution[s];
         g.dataOff = (int)gridFloats;
         fill_bounds(g);
+        fill_keep_boxes(g, d->sdf_data[s]);
         gridFloats = align_up(gridFloats + (size_t)g.dimx * g.dimy * g.dimz, 64);
         DARTK_REQUIRE(gridFloats < (size_t)1 << 31, "SDF arena exceeds 2^31 voxels");
     }
@@ -312,6 +335,8 @@ int dartk_model_create(const dartk_model_desc *d, dartk_model_t *out) {
     if (obsVoxels) fill_bounds(v.obs);
     v.obsData = (float *)(base + o_obs);
     m->obsVoxels = obsVoxels;
+    m->uniformRes = true;
+    for (int s = 1; s < nS; ++s) if (d->sdf_resolution[s] != d->sdf_resolution[0]) m->uniformRes = false;
     m->dtTmp = nullptr;
     if (obsVoxels) DARTK_HIP(hipMalloc((void **)&m->dtTmp, obsVoxels * sizeof(float)));
     *out = reinterpret_cast<dartk_model_t>(m);

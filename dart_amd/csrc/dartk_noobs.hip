@@ -4,9 +4,9 @@
 //
 // The reference evaluates ~2500 contact priors one by one on the host (host SDF reads, sparse coeffRef inserts into a
 // 7.5k-dimensional system whose prior rows are identically zero, SURVEY A-7) around three blocking kernel round trips
-// per iteration. Here one iteration of ALL candidates of a batch is two launches:
-//   noobs_terms_kernel  grid (tiles of every term, candidate): self-intersection, pairwise intersection and contact
-//                       priors, each tile -> one partial packed system (deterministic slabs, no float atomics)
+// per iteration. Here one iteration of ALL candidates of a batch is a handful of launches:
+//   noobs_terms_kernel  one launch per term, grid (workgroups of the term, candidate): self-intersection, pairwise
+//                       intersection, contact priors; each workgroup -> one partial packed system (deterministic slabs)
 //   noobs_solve_kernel  grid (candidate), one wave: fixed-order reduction of the candidate's slabs, assembly in the
 //                       reference's order, regularisation + LM damping, the reference's upper-triangular back
 //                       substitution (SURVEY A-1), pose update with joint clamps, forward kinematics
@@ -27,7 +27,6 @@ static constexpr int NOOBS_MAX_TERMS = DARTK_MAX_MODELS * DARTK_MAX_MODELS + 1;
 struct NoObsTerm {
     int type, src, dst;
     int nPoints, nBlocks;        // points (cloud sites / priors) and workgroups (= slabs) of this term per candidate
-    int blockStart;              // first blockIdx.x of the term
     int dims, S;                 // dimension / packed length of the term's system
     int slabOff;                 // offset (floats) of the term's slabs inside a candidate's slab area
     const float4 *cloud;
@@ -43,10 +42,26 @@ struct NoObsProblem {            // device-visible description shared by both ke
     int dims[DARTK_MAX_MODELS];
     int poseOff[DARTK_MAX_MODELS];   // offset of model m's pose block inside a candidate's pose record
     int jointOff[DARTK_MAX_MODELS];
+    int uniformRes[DARTK_MAX_MODELS];   // 1 when all SDFs of the model share one resolution
     ModelView model[DARTK_MAX_MODELS];   // static tables only; pose pointers are rebased per candidate
     NoObsTerm term[NOOBS_MAX_TERMS];
     const dartk_contact_prior *priors;
 };
+
+#ifdef DARTK_STAMPS
+// diagnostic build only: cycles of thread 0 of every workgroup per phase, summed per term type
+__device__ unsigned long long g_noobsStamps[3][8];
+#define NOOBS_STAMP(ph) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); atomicAdd(&g_noobsStamps[TYPE][ph], now_ - stampT); stampT = now_; } } while (0)
+#else
+#define NOOBS_STAMP(ph) do { } while (0)
+#endif
+
+// LDS row length of a term: the packed-system row, and at least the parked state of an active point (8 / 16 floats)
+__host__ __device__ inline int noobs_row_len(int type, int d) {
+    const int ld = tile_row_len(d, type == TERM_PRIORS);
+    const int need = type == TERM_PRIORS ? 16 : 8;
+    return ld > need ? ld : need;
+}
 
 // pose block of one model of one candidate: T_mc | T_cm | joints | T_mf | T_fm
 __device__ __forceinline__ ModelView rebase(const ModelView &s, float *pose) {
@@ -81,31 +96,32 @@ noobs_load_poses_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ 
 }
 
 // -----------------------------------------------------------------------------------------------------
-// all terms of one iteration. LDS: per model [T_fm | T_mf] (24*nFrames) | rows | wave counters | scalars
+// one term of one iteration, grid (workgroups of the term, candidate); one instantiation per term type so that the
+// register budget of the contact-prior path does not set the occupancy of the intersection paths.
+// LDS: per model [T_fm | T_mf] (24*nFrames) | per model spheres (20*nSdfs) | rows | wave counters | potential-intersection matrix (self term)
 // -----------------------------------------------------------------------------------------------------
-template <int PPT>
+template <int TPT, int TYPE>
 __global__ void __launch_bounds__(NE_BLOCK)
-noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses, float *__restrict__ slabs, int ldMax) {
+noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses, float *__restrict__ slabs, int termIdx, int potLdsInts) {
     extern __shared__ float lds[];
-    __shared__ int sTerm;
+#ifdef DARTK_STAMPS
+    unsigned long long stampT = clock64();
+#endif
     __shared__ float sT_ds[24];
     __shared__ double sErr[NE_BLOCK / 64];
+    __shared__ int sOff[DARTK_MAX_MODELS + 1];
+    __shared__ int sSphOff[DARTK_MAX_MODELS + 1];
     const int c = blockIdx.y;
-    if (threadIdx.x == 0) {
-        int t = 0;
-        while (t + 1 < P->nTerms && (int)blockIdx.x >= P->term[t + 1].blockStart) ++t;
-        sTerm = t;
-    }
-    __syncthreads();
-    const NoObsTerm &T = P->term[sTerm];
+    const NoObsTerm &T = P->term[termIdx];
     const int nModels = P->nModels;
     float *poseC = poses + (size_t)c * P->poseStride;
     // stage every model's frame transforms: model mi at lds + sOff[mi] as [T_fm | T_mf]
-    __shared__ int sOff[DARTK_MAX_MODELS + 1];
     if (threadIdx.x == 0) {
         int o = 0;
         for (int mi = 0; mi < nModels; ++mi) { sOff[mi] = o; o += 24 * P->model[mi].nFrames; }
         sOff[nModels] = o;
+        for (int mi = 0; mi < nModels; ++mi) { sSphOff[mi] = o; o += kSphereStride * P->model[mi].nSdfs; }
+        sSphOff[nModels] = o;
     }
     __syncthreads();
     for (int mi = 0; mi < nModels; ++mi) {
@@ -115,14 +131,30 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         for (int i = threadIdx.x; i < n; i += blockDim.x) { p[i] = mv.T_fm[i]; p[n + i] = mv.T_mf[i]; }
     }
 #define sTf(mi) (lds + sOff[mi])
-    float *rows = lds + sOff[nModels];
-    int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ldMax);
+#define sSph(mi) (lds + sSphOff[mi])
+    __syncthreads();
+    // bounding spheres of every SDF's keep boxes in its model's frame (see make_spheres)
+    for (int mi = 0; mi < nModels; ++mi) {
+        const ModelView &mv = P->model[mi];
+        for (int g = threadIdx.x; g < mv.nSdfs; g += blockDim.x)
+            make_spheres(mv.sdfs[g], sTf(mi) + 12 * mv.nFrames + 12 * mv.sdfFrame[g], sSph(mi) + kSphereStride * g);
+    }
     const int d = T.dims;
-    const bool weighted = (T.type == TERM_PRIORS);
-    const int ld = row_len(d, weighted);
+    const int ld = noobs_row_len(TYPE, d);
+    float *rows = lds + sSphOff[nModels];
+    int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ld);
+    int *sPot = waveCnt + 8;            // the self term's potential-intersection matrix (when it fits)
     const ModelView src = rebase(P->model[T.src], poseC + P->poseOff[T.src]);
     const ModelView dst = rebase(P->model[T.dst], poseC + P->poseOff[T.dst]);
-    if (T.type == TERM_INTER && threadIdx.x == 0) {      // T_ds = T_mc(dst) * T_cm(src), T_sd = inverse (optimizer.cpp:396-397)
+    const int *potPtr = T.pot;
+    if (TYPE == TERM_SELF) {
+        const int nn = src.nSdfs * src.nSdfs;
+        if (nn <= potLdsInts) {
+            for (int i = threadIdx.x; i < nn; i += blockDim.x) sPot[i] = T.pot[i];
+            potPtr = sPot;
+        }
+    }
+    if (TYPE == TERM_INTER && threadIdx.x == 0) {      // T_ds = T_mc(dst) * T_cm(src), T_sd = inverse (optimizer.cpp:396-397)
         float A[12], B[12], T_ds[12], T_sd[12];
         for (int i = 0; i < 12; ++i) { A[i] = dst.T_mc[i]; B[i] = src.T_cm[i]; }
         se3_mul(A, B, T_ds);
@@ -131,10 +163,64 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     }
     __syncthreads();
 
-    PairAcc<NE_BLOCK, PPT> acc;
-    acc.init(d, false, weighted);
+    NOOBS_STAMP(0);
+    TileAcc<NE_BLOCK, TPT> acc;
+    acc.init(d);
+    NOOBS_STAMP(1);
+    const int lOff = tile_l_off(d, TYPE == TERM_PRIORS);
     double errInactive = 0.0;       // contact priors: _error of priors that contribute no row
-    const int localBlock = blockIdx.x - T.blockStart;
+    // rows of the parked points [0, n): Jacobians by the first n threads, then every thread adds its packed entries
+    auto flush = [&](int n) {
+        __syncthreads();
+        NOOBS_STAMP(3);
+        if ((int)threadIdx.x < n) {
+            float *row = rows + threadIdx.x * ld;
+            f3 pm, gs;
+            pm.x = row[0]; pm.y = row[1]; pm.z = row[2]; gs.x = row[3]; gs.y = row[4]; gs.z = row[5];
+            const float residual = row[6];
+            const int packed = __float_as_int(row[7]);
+            if constexpr (TYPE == TERM_PRIORS) {
+                // subJ = [ dot(grad_sm, J3D_src) | -dot(grad_dm, J3D_dst) ] placed at the models' global offsets (:110-126)
+                f3 pdm, gdm;
+                pdm.x = row[8]; pdm.y = row[9]; pdm.z = row[10]; gdm.x = row[11]; gdm.y = row[12]; gdm.z = row[13];
+                const float weight = row[14], E = row[15];
+                const int srcFrame = packed & 0xff, dstFrame = (packed >> 8) & 0xff, pSrc = (packed >> 16) & 0xf, pDst = (packed >> 20) & 0xf;
+                const bool upSrc = (packed >> 24) & 1, upDst = (packed >> 25) & 1;
+                for (int i = 0; i < ld; ++i) row[i] = 0.0f;
+                float *L = row + lOff;
+                const ModelView &ms = P->model[pSrc];
+                const ModelView &md = P->model[pDst];
+                if (upSrc)
+                    error_jacobian<false>(L + P->off[pSrc], pm, 1.0f, ms.depMask[srcFrame], gs, ms.nJoints, ms.jointType, ms.jointAxis,
+                                          sTf(pSrc), sTf(pSrc) + 12 * ms.nFrames);
+                if (upDst) {
+                    float *rd = L + P->off[pDst];
+                    error_jacobian<false>(rd, pdm, 1.0f, md.depMask[dstFrame], gdm, md.nJoints, md.jointType, md.jointAxis,
+                                          sTf(pDst), sTf(pDst) + 12 * md.nFrames);
+                    const int nd = 6 + md.nJoints;
+                    for (int i = 0; i < nd; ++i) rd[i] = -rd[i];
+                }
+                L[d] = 1.0f;
+                row[0] = weight * residual;         // J^T e += (w*err) * J   (:128)
+                row[1] = E;
+                for (int i = 0; i < d; ++i) row[2 + i] = weight * L[i];      // (w*J) J^T   (:129)
+            } else {
+                for (int i = d + 3; i < ld; ++i) row[i] = 0.0f;
+                error_jacobian<TYPE == TERM_SELF>(row + 2, pm, 1.0f, src.depMask[packed], gs, src.nJoints, src.jointType, src.jointAxis,
+                                                  sTf(T.src), sTf(T.src) + 12 * src.nFrames);
+                row[0] = residual;
+                row[1] = (float)(0.5 * (double)residual * (double)residual);
+                row[d + 2] = 1.0f;
+            }
+        }
+        __syncthreads();
+        NOOBS_STAMP(4);
+        if (n) acc.template accumulate<TYPE == TERM_PRIORS>(rows, ld, n, lOff);
+        __syncthreads();
+        NOOBS_STAMP(5);
+    };
+    int pending = 0;
+    const int localBlock = blockIdx.x;
     const int nTiles = (T.nPoints + NE_BLOCK - 1) / NE_BLOCK;
     for (int tile = localBlock; tile < nTiles; tile += T.nBlocks) {
         const int index = tile * NE_BLOCK + threadIdx.x;
@@ -147,12 +233,12 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         float residual = 0.0f, weight = 0.0f, E = 0.0f;
         bool upSrc = true, upDst = false;
         if (index < T.nPoints) {
-            if (T.type == TERM_SELF) {
+            if constexpr (TYPE == TERM_SELF) {
                 const float4 v = T.cloud[index];
                 const int srcGrid = (int)roundf(v.w);
                 srcFrame = src.sdfFrame[srcGrid];
                 pm = se3_apply_w(sTf(T.src) + 12 * src.nFrames + 12 * srcFrame, v.x, v.y, v.z, 1.0f);
-                const Collision col = first_collision(src, sTf(T.src), pm, T.pot, srcGrid);
+                const Collision col = first_collision(src, sTf(T.src), pm, potPtr, srcGrid, sSph(T.src));
                 if (col.hit) {
                     const SdfDev &s = src.sdfs[col.dstGrid];
                     const f3 gf = grid_gradient(src.grids + s.dataOff, s.dimx, s.dimy, col.vg);
@@ -160,13 +246,13 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                     residual = col.residual;
                     active = true;
                 }
-            } else if (T.type == TERM_INTER) {
+            } else if constexpr (TYPE == TERM_INTER) {
                 const float4 v = T.cloud[index];
                 const int srcGrid = (int)roundf(v.w);
                 srcFrame = src.sdfFrame[srcGrid];
                 pm = se3_apply_w(sTf(T.src) + 12 * src.nFrames + 12 * srcFrame, v.x, v.y, v.z, 1.0f);
                 const f3 vdm = se3_apply_w(sT_ds, pm.x, pm.y, pm.z, 1.0f);
-                const Collision col = first_collision(dst, sTf(T.dst), vdm, nullptr, 0);
+                const Collision col = first_collision(dst, sTf(T.dst), vdm, nullptr, 0, sSph(T.dst));
                 if (col.hit) {
                     const SdfDev &s = dst.sdfs[col.dstGrid];
                     const f3 gf = grid_gradient(dst.grids + s.dataOff, s.dimx, s.dimy, col.vg);
@@ -192,13 +278,19 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                     pdm = se3_apply_w(md.T_mc, cc.x, cc.y, cc.z, 1.0f);
                     // nearest destination SDF by raw voxel-unit value among isInBoundsInterp grids (:41-54; the
                     // reference loop bound `<= getNumSdfs()` reads one element past the end -- restated with `<`)
+                    // With one resolution for all of the model's SDFs the raw-value arg-min and the metric gate order alike,
+                    // so SDFs that cannot come within the contact threshold are skipped (same outcome: either the same
+                    // nearest SDF, or every SDF is beyond the threshold and the prior returns sign*w*threshold).
+                    const int slot = P->uniformRes[pDst] ? keep_slot(pr.contactThreshold) : -1;
                     int dstSdf = -1;
                     float minV = 3.402823466e+38f;
+                    const float *sph = sSph(pDst) + 4 * (slot < 0 ? 4 : slot);
                     for (int ds = 0; ds < md.nSdfs; ++ds) {
-                        const f3 df = se3_apply_w(dfm + 12 * md.sdfFrame[ds], pdm.x, pdm.y, pdm.z, 1.0f);
+                        if (sphere_reject(sph + kSphereStride * ds, pdm)) continue;
                         const SdfDev &s = md.sdfs[ds];
+                        const f3 df = se3_apply_w(dfm + 12 * md.sdfFrame[ds], pdm.x, pdm.y, pdm.z, 1.0f);
                         const f3 g = grid_coords(s, df);
-                        if (!in_bounds_interp(s, g)) continue;
+                        if (!in_bounds_interp(s, g) || !in_keep_box(s, slot, g)) continue;
                         const float v = grid_value(md.grids + s.dataOff, s.dimx, s.dimy, g);
                         if (v < minV) { minV = v; dstSdf = ds; }
                     }
@@ -241,48 +333,28 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                 if (!active) errInactive += (double)E;
             }
         }
+        // Active points are rare and scattered over the lanes: park their state (compacted, in evaluation order) in the
+        // row buffer and build the Jacobian rows later, densely, one thread per parked point.
+        NOOBS_STAMP(2);
         int nActive;
         const int slot = compact_slot<NE_BLOCK>(active, waveCnt, nActive);
+        if (pending + nActive > NE_BLOCK) { flush(pending); pending = 0; }
         if (active) {
-            float *row = rows + slot * ld;
-            if (T.type == TERM_SELF) {
-                error_jacobian<true>(row, pm, 1.0f, src.depMask[srcFrame], gs, src.nJoints, src.jointType, src.jointAxis,
-                                     sTf(T.src), sTf(T.src) + 12 * src.nFrames);
-                row[d] = residual;
-                row[d + 1] = (float)(0.5 * (double)residual * (double)residual);
-                row[d + 2] = 1.0f;
-            } else if (T.type == TERM_INTER) {
-                error_jacobian<false>(row, pm, 1.0f, src.depMask[srcFrame], gs, src.nJoints, src.jointType, src.jointAxis,
-                                      sTf(T.src), sTf(T.src) + 12 * src.nFrames);
-                row[d] = residual;
-                row[d + 1] = (float)(0.5 * (double)residual * (double)residual);
-                row[d + 2] = 1.0f;
+            float *e = rows + (pending + slot) * ld;
+            e[0] = pm.x; e[1] = pm.y; e[2] = pm.z; e[3] = gs.x; e[4] = gs.y; e[5] = gs.z; e[6] = residual;
+            if constexpr (TYPE == TERM_PRIORS) {
+                e[7] = __int_as_float(srcFrame | (dstFrame << 8) | (pSrc << 16) | (pDst << 20) | ((int)upSrc << 24) | ((int)upDst << 25));
+                e[8] = pdm.x; e[9] = pdm.y; e[10] = pdm.z; e[11] = gdm.x; e[12] = gdm.y; e[13] = gdm.z; e[14] = weight; e[15] = E;
             } else {
-                // subJ = [ dot(grad_sm, J3D_src) | -dot(grad_dm, J3D_dst) ] placed at the models' global offsets (:110-126)
-                for (int i = 0; i < d; ++i) row[i] = 0.0f;
-                const ModelView &ms = P->model[pSrc];
-                const ModelView &md = P->model[pDst];
-                if (upSrc)
-                    error_jacobian<false>(row + P->off[pSrc], pm, 1.0f, ms.depMask[srcFrame], gs, ms.nJoints, ms.jointType, ms.jointAxis,
-                                          sTf(pSrc), sTf(pSrc) + 12 * ms.nFrames);
-                if (upDst) {
-                    float *rd = row + P->off[pDst];
-                    error_jacobian<false>(rd, pdm, 1.0f, md.depMask[dstFrame], gdm, md.nJoints, md.jointType, md.jointAxis,
-                                          sTf(pDst), sTf(pDst) + 12 * md.nFrames);
-                    const int nd = 6 + md.nJoints;
-                    for (int i = 0; i < nd; ++i) rd[i] = -rd[i];
-                }
-                row[d] = weight * residual;         // J^T e += (w*err) * J   (:128)
-                row[d + 1] = E;
-                row[d + 2] = 1.0f;
-                for (int i = 0; i < d; ++i) row[d + 3 + i] = weight * row[i];      // (w*J) J^T   (:129)
+                e[7] = __int_as_float(srcFrame);
             }
         }
+        pending += nActive;
         __syncthreads();
-        if (nActive) acc.accumulate(rows, ld, nActive);
-        __syncthreads();
+        NOOBS_STAMP(3);
     }
-    if (T.type == TERM_PRIORS) {    // add the _error of the row-less priors to the e slot, fixed order
+    flush(pending);
+    if constexpr (TYPE == TERM_PRIORS) {    // add the _error of the row-less priors to the e slot, fixed order
         double v = errInactive;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -290,11 +362,13 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         __syncthreads();
         double tot = 0.0;
         for (int w = 0; w < NE_BLOCK / 64; ++w) tot += sErr[w];
-        acc.add_at(T.S - 1, tot);
+        acc.add_e(d, tot);
     }
     float *slab = slabs + (size_t)c * P->slabStride + T.slabOff + (size_t)localBlock * T.S;
-    acc.store(slab, T.S);
+    acc.store(slab, d);
+    NOOBS_STAMP(6);
 #undef sTf
+#undef sSph
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -444,8 +518,8 @@ struct NoObs {
     int nPriors;
     int maxBatch;
     float *poses, *slabs;
-    int totalBlocks, ldMax, SMax, maxFrames;
-    size_t ldsTerms, ldsSolve;
+    int SMax, maxFrames, potLdsInts;
+    size_t ldsTerm[NOOBS_MAX_TERMS], ldsSolve;
     bool lambdaActive[DARTK_MAX_MODELS * DARTK_MAX_MODELS];
 };
 
@@ -453,7 +527,50 @@ struct NoObs {
 
 using namespace dartk;
 
+template <int TPT, int TYPE>
+static int noobs_launch_term(NoObs *t, int term, int batch, hipStream_t st) {
+    auto kfn = noobs_terms_kernel<TPT, TYPE>;
+    const size_t lds = t->ldsTerm[term];
+    if (lds > 64 * 1024) DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kfn, dim3(t->h.term[term].nBlocks, batch), dim3(NE_BLOCK), lds, st, t->d, t->poses, t->slabs, term, t->potLdsInts);
+    return DARTK_OK;
+}
+
+template <int TYPE>
+static int noobs_launch_term_ppt(NoObs *t, int term, int batch, hipStream_t st) {
+    const int tiles = tile_count(t->h.term[term].dims);     // 4x4 tiles of the packed system per workgroup
+    if (tiles <= NE_BLOCK) return noobs_launch_term<1, TYPE>(t, term, batch, st);
+    if (tiles <= 2 * NE_BLOCK) return noobs_launch_term<2, TYPE>(t, term, batch, st);
+    set_error("term %d: system dimension %d needs more than %d accumulator tiles", term, t->h.term[term].dims, 2 * NE_BLOCK);
+    return DARTK_ERR_UNSUPPORTED;
+}
+
+// one launch per term (the terms write disjoint slabs; the solve kernel that follows reads them all)
+static int noobs_launch_terms(NoObs *t, int batch, hipStream_t st) {
+    ProfScope ps(DARTK_PROF_NOOBS_TERMS, st);
+    for (int i = 0; i < t->h.nTerms; ++i) {
+        int rc;
+        switch (t->h.term[i].type) {
+        case TERM_SELF: rc = noobs_launch_term_ppt<TERM_SELF>(t, i, batch, st); break;
+        case TERM_INTER: rc = noobs_launch_term_ppt<TERM_INTER>(t, i, batch, st); break;
+        default: rc = noobs_launch_term_ppt<TERM_PRIORS>(t, i, batch, st); break;
+        }
+        if (rc) return rc;
+    }
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
 extern "C" {
+
+#ifdef DARTK_STAMPS
+int dartk_debug_noobs_stamps(unsigned long long *out24, int reset) {
+    DARTK_HIP(hipDeviceSynchronize());
+    DARTK_HIP(hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_noobsStamps), sizeof(unsigned long long) * 24));
+    if (reset) { unsigned long long z[24] = {0}; DARTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_noobsStamps), z, sizeof(z))); }
+    return DARTK_OK;
+}
+#endif
 
 int dartk_noobs_destroy(dartk_noobs_t h) {
     NoObs *t = reinterpret_cast<NoObs *>(h);
@@ -486,6 +603,7 @@ int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *co
         P.poseOff[m] = poseOff; poseOff += pose_block_floats(mod->v);
         P.jointOff[m] = jointOff; jointOff += mod->v.nJoints;
         if (mod->v.nFrames > maxFrames) maxFrames = mod->v.nFrames;
+        P.uniformRes[m] = mod->uniformRes ? 1 : 0;
     }
     if (D > 64) { delete t; set_error("global system dimension %d exceeds 64 (one lane per unknown in the solve)", D); return DARTK_ERR_UNSUPPORTED; }
     P.D = D; P.poseStride = poseOff; P.jointStride = jointOff > 0 ? jointOff : 1;
@@ -505,18 +623,23 @@ int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *co
     }
     // term table in the reference's evaluation order: per model self-intersection, then the other models; priors last
     const bool small = maxBatch < 64;     // few candidates: one workgroup per tile; many: a few workgroups per term
-    int nTerms = 0, block = 0, slabOff = 0, SMax = 0, ldMax = 0;
+    int nTerms = 0, slabOff = 0, SMax = 0;
+    int ldsModels = 0, potInts = 0;
+    for (int m = 0; m < nModels; ++m) {
+        ldsModels += 24 * P.model[m].nFrames + kSphereStride * P.model[m].nSdfs;
+        if (P.model[m].nSdfs * P.model[m].nSdfs > potInts) potInts = P.model[m].nSdfs * P.model[m].nSdfs;
+    }
+    t->potLdsInts = potInts <= 4096 ? potInts : 0;
     auto add = [&](int type, int src, int dst, int nPoints, int dims, const float *cloud, const int *pot) {
         NoObsTerm &T = P.term[nTerms++];
         T.type = type; T.src = src; T.dst = dst; T.nPoints = nPoints; T.dims = dims; T.S = sys_size(dims);
         const int tiles = (nPoints + NE_BLOCK - 1) / NE_BLOCK;
         T.nBlocks = small ? (tiles > 0 ? tiles : 1) : (tiles < 4 ? (tiles > 0 ? tiles : 1) : 4);
-        T.blockStart = block; block += T.nBlocks;
         T.slabOff = slabOff; slabOff += T.nBlocks * T.S;
         T.cloud = reinterpret_cast<const float4 *>(cloud); T.pot = pot;
         if (T.S > SMax) SMax = T.S;
-        const int ld = row_len(dims, type == TERM_PRIORS);
-        if (ld > ldMax) ldMax = ld;
+        const int ld = noobs_row_len(type, dims);
+        t->ldsTerm[nTerms - 1] = sizeof(float) * ((size_t)ldsModels + (size_t)NE_BLOCK * ld + 8 + (type == TERM_SELF ? t->potLdsInts : 0));
     };
     for (int m = 0; m < nModels; ++m) {
         if (h_lambdaIntersection[m + m * nModels] > 0 && nCloudPoints[m] > 0 && P.dims[m] > 6) {
@@ -532,14 +655,13 @@ int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *co
     if (nPriors > 0) add(TERM_PRIORS, 0, 0, nPriors, D, nullptr, nullptr);
     for (int i = 0; i < nModels * nModels; ++i) t->lambdaActive[i] = h_lambdaIntersection[i] > 0;
     P.nTerms = nTerms; P.slabStride = slabOff > 0 ? slabOff : 1;
-    t->totalBlocks = block; t->SMax = SMax; t->ldMax = ldMax; t->maxFrames = maxFrames; t->maxBatch = maxBatch; t->nPriors = nPriors;
-    int ldsModels = 0;
-    for (int m = 0; m < nModels; ++m) ldsModels += 24 * P.model[m].nFrames;
-    t->ldsTerms = sizeof(float) * ((size_t)ldsModels + (size_t)NE_BLOCK * ldMax + 8);
+    t->SMax = SMax; t->maxFrames = maxFrames; t->maxBatch = maxBatch; t->nPriors = nPriors;
+    size_t ldsTermMax = 0;
+    for (int i = 0; i < nTerms; ++i) if (t->ldsTerm[i] > ldsTermMax) ldsTermMax = t->ldsTerm[i];
     const int ldU = (D + 1) | 1;
     const int sysFloats = SMax > 12 * maxFrames ? SMax : 12 * maxFrames;
     t->ldsSolve = sizeof(float) * ((size_t)D * ldU + D + sysFloats + 8);
-    if (t->ldsTerms > 160 * 1024 || t->ldsSolve > 160 * 1024) { delete t; set_error("LDS requirement exceeds 160 KiB"); return DARTK_ERR_UNSUPPORTED; }
+    if (ldsTermMax > 160 * 1024 || t->ldsSolve > 160 * 1024) { delete t; set_error("LDS requirement exceeds 160 KiB"); return DARTK_ERR_UNSUPPORTED; }
     hipError_t e = hipSuccess;
     if (nPriors > 0) {
         e = hipMalloc((void **)&t->d_priors, sizeof(dartk_contact_prior) * (size_t)nPriors);
@@ -569,25 +691,6 @@ int dartk_noobs_set_priors(dartk_noobs_t h, const dartk_contact_prior *h_priors,
         DARTK_HIP(hipMemcpyAsync(t->d_priors, h_priors, sizeof(dartk_contact_prior) * (size_t)nPriors, hipMemcpyHostToDevice, as_stream(stream)));
         DARTK_HIP(hipStreamSynchronize(as_stream(stream)));
     }
-    return DARTK_OK;
-}
-
-static int noobs_launch_terms(NoObs *t, int batch, hipStream_t st) {
-    const dim3 grid(t->totalBlocks, batch), block(NE_BLOCK);
-    if (t->totalBlocks == 0) return DARTK_OK;
-    ProfScope ps(DARTK_PROF_NOOBS_TERMS, st);
-#define DARTK_LAUNCH_TERMS(PPT_)                                                                                 \
-    do {                                                                                                         \
-        auto kfn = noobs_terms_kernel<PPT_>;                                                                     \
-        if (t->ldsTerms > 64 * 1024)                                                                             \
-            DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->ldsTerms)); \
-        hipLaunchKernelGGL(kfn, grid, block, t->ldsTerms, st, t->d, t->poses, t->slabs, t->ldMax);               \
-    } while (0)
-    if (t->SMax <= 3 * NE_BLOCK) DARTK_LAUNCH_TERMS(3);
-    else if (t->SMax <= 6 * NE_BLOCK) DARTK_LAUNCH_TERMS(6);
-    else DARTK_LAUNCH_TERMS(20);
-#undef DARTK_LAUNCH_TERMS
-    DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
 

@@ -93,13 +93,14 @@ assoc_multi_kernel(const float4 *__restrict__ vert, int nPix, const MultiArgs *_
                 f3 pn; pn.x = args->pn[mi][0]; pn.y = args->pn[mi][1]; pn.z = args->pn[mi][2];
                 if (!(dot(xm, pn) >= args->planeOffset[mi])) continue;
                 const float thr = args->distThr[mi];
+                const int slot = keep_slot(thr);
                 const float *__restrict__ T_fm = m.T_fm;
                 for (int g = 0; g < m.nSdfs; ++g) {
                     const int f = m.sdfFrame[g];
                     const f3 xf = se3_apply_w(T_fm + 12 * f, xm.x, xm.y, xm.z, xc.w);
                     const SdfDev &s = m.sdfs[g];
                     const f3 xg = grid_coords(s, xf);
-                    if (!in_bounds_grad_interp(s, xg)) continue;
+                    if (!in_bounds_grad_interp(s, xg) || !in_keep_box(s, slot, xg)) continue;
                     const float d = grid_value(m.grids + s.dataOff, s.dimx, s.dimy, xg) * s.res;
                     if (d < sdfError) {
                         if (d * d < thr * thr) { sdfError = d; aGrid = g; aModel = mi; }
@@ -203,7 +204,7 @@ ne_obs2mod_kernel(const dartk_da_point *__restrict__ pts, const float4 *__restri
 
 size_t ne_obs2mod_lds_bytes(const ModelView &m, int d, int red) {
     const int fullDims = 6 + m.nJoints;
-    size_t words = 24 * (size_t)m.nFrames + 16 * (size_t)m.nSdfs + (size_t)NE_BLOCK * row_len(d, red != 0);
+    size_t words = 24 * (size_t)m.nFrames + (sizeof(SdfDev) / 4) * (size_t)m.nSdfs + (size_t)NE_BLOCK * row_len(d, red != 0);
     if (red) words += (size_t)NE_BLOCK * (fullDims | 1);
     return words * sizeof(float);
 }

@@ -25,16 +25,19 @@ __host__ __device__ inline int row_len(int d, bool drop) {
     return n | 1;
 }
 
+// weighted rows (contact priors): [ J | r | E | 1 | w ], J^T J entry (i,j), j <= i, accumulates (w*J_j)*J_i
+__host__ __device__ inline int row_len_w(int d) { return (d + 4) | 1; }
+
 template <int BLOCK, int PPT>
 struct PairAcc {
     float acc[PPT];
     int ia[PPT], ib[PPT];
 
-    // drop: J^T J from the second copy of the row (both factors); weighted: first factor from the second copy
-    // (w*J), second from the plain row (ContactPrior's w*J*J^T, contact_prior.cpp:129)
+    // drop: J^T J from the second copy of the row (both factors); weighted: (w*J_j)*J_i with the weight read from the
+    // row (ContactPrior's w*J*J^T, contact_prior.cpp:129) -- use accumulate_w() then
     __device__ __forceinline__ void init(int d, bool drop, bool weighted = false) {
         const int S = sys_size(d);
-        const int base = (drop || weighted) ? d + 3 : 0;
+        const int base = drop ? d + 3 : 0;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int o = (int)threadIdx.x + k * BLOCK;
@@ -48,7 +51,7 @@ struct PairAcc {
                 while (((i * (i + 1)) >> 1) > t) --i;
                 while ((((i + 1) * (i + 2)) >> 1) <= t) ++i;
                 const int j = t - ((i * (i + 1)) >> 1);
-                if (weighted) { a = base + j; b = i; }
+                if (weighted) { a = j; b = i; }
                 else { a = base + i; b = base + j; }
             }
             ia[k] = a; ib[k] = b;
@@ -77,6 +80,22 @@ struct PairAcc {
         }
     }
 
+    // weighted rows: J^T J slots multiply by the row's weight first, every other slot by the constant 1 of the row
+    __device__ __forceinline__ void accumulate_w(const float *rows, int ld, int n, int d) {
+        int iw[PPT];
+        const int S = sys_size(d);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int o = (int)threadIdx.x + k * BLOCK;
+            iw[k] = (o >= d && o < S - 1) ? d + 3 : d + 2;
+        }
+        for (int p = 0; p < n; ++p) {
+            const float *r0 = rows + p * ld;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) acc[k] = __builtin_fmaf(r0[iw[k]] * r0[ia[k]], r0[ib[k]], acc[k]);
+        }
+    }
+
     // add v to output slot o (by the thread that owns it)
     __device__ __forceinline__ void add_at(int o, double v) {
 #pragma unroll
@@ -89,6 +108,120 @@ struct PairAcc {
         for (int k = 0; k < PPT; ++k) {
             const int o = (int)threadIdx.x + k * BLOCK;
             if (o < S) slab[o] = acc[k];
+        }
+    }
+};
+
+// Register-tiled variant for the batched (NoObs) terms, where the row reduction is the LDS-bound part: a row holds
+//   R = [ r | E | Jw_0 .. Jw_{d-1} | .. ]      L = [ J_0 .. J_{d-1} | 1 | 0.. ]
+// with r the effective residual and Jw the (weighted) Jacobian. Unweighted rows (Jw == J) store one array
+// [ r | E | J | 1 | 0.. ] and L aliases it at offset 2; weighted rows store L after R (offset tile_pad(d+2)).
+// The packed system is read off the outer product
+// M[i][c] = sum_rows L_i * R_c:  J^T e_i = M[i][0],  e = M[d][1],  J^T J (i, j<=i) = M[i][2+j]. A thread owns 4x4 tiles of
+// M (two 16-byte LDS reads feed 16 FMAs); only tiles that hold a wanted entry are enumerated. Every entry is still ONE
+// fma chain over the rows in their order, so the sums are bit-identical to PairAcc's.
+__host__ __device__ inline int tile_pad(int n) { return (n + 3) & ~3; }
+__host__ __device__ inline int tile_l_off(int d, bool weighted) { return weighted ? tile_pad(d + 2) : 2; }
+__host__ __device__ inline int tile_row_len(int d, bool weighted) { return tile_pad(tile_l_off(d, weighted) + tile_pad(d + 1)); }
+__host__ __device__ inline int tile_jmax(int I, int d) {        // last wanted column tile of row tile I
+    const int imax = (4 * I + 3 < d - 1) ? 4 * I + 3 : d - 1;
+    return (imax + 2) >> 2;
+}
+__host__ __device__ inline int tile_count(int d) {
+    int n = 0;
+    for (int I = 0; 4 * I < d + 1; ++I) n += tile_jmax(I, d) + 1;
+    return n;
+}
+
+template <int BLOCK, int TPT>
+struct TileAcc {
+    float acc[TPT][16];
+    int I[TPT], J[TPT];       // tile coordinates, I < 0: idle
+
+    __device__ __forceinline__ void init(int d) {
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            int t = (int)threadIdx.x + k * BLOCK;
+            I[k] = -1; J[k] = 0;
+            for (int i = 0; 4 * i < d + 1; ++i) {
+                const int n = tile_jmax(i, d) + 1;
+                if (t < n) { I[k] = i; J[k] = t; break; }
+                t -= n;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[k][e] = 0.0f;
+        }
+    }
+
+    // rows: LDS, 16-byte aligned, n rows of stride ld (a multiple of 4); lOff = tile_l_off() (2: 8-byte aligned L quads)
+    template <bool WEIGHTED>
+    __device__ __forceinline__ void load_row(const float *pl, const float *pr, float *lv, float *rv) const {
+        if (WEIGHTED) {
+            const float4 l = *reinterpret_cast<const float4 *>(pl);
+            lv[0] = l.x; lv[1] = l.y; lv[2] = l.z; lv[3] = l.w;
+        } else {
+            const float2 l0 = *reinterpret_cast<const float2 *>(pl), l1 = *reinterpret_cast<const float2 *>(pl + 2);
+            lv[0] = l0.x; lv[1] = l0.y; lv[2] = l1.x; lv[3] = l1.y;
+        }
+        const float4 r = *reinterpret_cast<const float4 *>(pr);
+        rv[0] = r.x; rv[1] = r.y; rv[2] = r.z; rv[3] = r.w;
+    }
+    __device__ __forceinline__ void fma_row(int k, const float *lv, const float *rv) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[k][4 * a + b] = __builtin_fmaf(lv[a], rv[b], acc[k][4 * a + b]);
+    }
+    template <bool WEIGHTED>
+    __device__ __forceinline__ void accumulate(const float *rows, int ld, int n, int lOff) {
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            if (I[k] < 0) continue;
+            const float *pl = rows + lOff + 4 * I[k], *pr = rows + 4 * J[k];
+            int p = 0;
+            for (; p + 4 <= n; p += 4, pl += 4 * ld, pr += 4 * ld) {       // four rows of loads in flight, rows added in order
+                float lv[4][4], rv[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) load_row<WEIGHTED>(pl + u * ld, pr + u * ld, lv[u], rv[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fma_row(k, lv[u], rv[u]);
+            }
+            for (; p < n; ++p, pl += ld, pr += ld) {
+                float lv[4], rv[4];
+                load_row<WEIGHTED>(pl, pr, lv, rv);
+                fma_row(k, lv, rv);
+            }
+        }
+    }
+
+    // add v to the e slot (by the thread that owns it)
+    __device__ __forceinline__ void add_e(int d, double v) {
+#pragma unroll
+        for (int k = 0; k < TPT; ++k)
+            if (I[k] == (d >> 2) && J[k] == 0) {
+                const int e = 4 * (d & 3) + 1;
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (q == e) acc[k][q] = (float)((double)acc[k][q] + v);
+            }
+    }
+
+    __device__ __forceinline__ void store(float *slab, int d) const {
+        const int S = sys_size(d);
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            if (I[k] < 0) continue;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = 4 * I[k] + a, c = 4 * J[k] + b;
+                    int o = -1;
+                    if (i < d && c == 0) o = i;
+                    else if (i == d && c == 1) o = S - 1;
+                    else if (i < d && c >= 2 && c - 2 <= i) o = d + ((i * (i + 1)) >> 1) + (c - 2);
+                    if (o >= 0) slab[o] = acc[k][4 * a + b];
+                }
         }
     }
 };

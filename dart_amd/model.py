@@ -378,13 +378,16 @@ class HostModel:
     def collision_cloud(self, density=1e5, seed=0):
         """Surface samples per geometry in the owning frame's coordinates, .w = SDF number. The reference draws
         from unseeded rand() (so its cloud changes run to run, Appendix A-18); here a seeded generator samples
-        the analytic primitive surfaces at the same density."""
+        the analytic primitive surfaces at the same density. The samples of one SDF are stored along a Z-order
+        curve (spatial.py: consecutive points are neighbours, which is what the device kernels' early exits need)."""
+        from .spatial import morton_order
         rng = np.random.default_rng(seed)
         pts = []
         for f in range(self.n_frames):
             s_num = self.frame_sdf[f] if self.frame_sdf else -1
             if s_num < 0:
                 continue
+            first = len(pts)
             for g in self.frame_geoms(f):
                 sc = g["scale"].astype(np.float64)
                 if g["type"] == GEOM_SPHERE:
@@ -416,6 +419,9 @@ class HostModel:
                     continue
                 world = se3.apply(g["T"], local.astype(F))
                 pts.append(np.concatenate([world.astype(F), np.full((len(world), 1), s_num, dtype=F)], axis=1))
+            if len(pts) > first:
+                grp = np.concatenate(pts[first:], axis=0)
+                pts[first:] = [grp[morton_order(grp[:, :3])]]
         if not pts:
             return np.zeros((0, 4), dtype=F)
         return np.ascontiguousarray(np.concatenate(pts, axis=0), dtype=F)
