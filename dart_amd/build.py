@@ -17,8 +17,16 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+FLAGS_FILE = os.path.join(HERE, ".libdartk.flags")      # the flags the existing library was built with
+
+
 def needs_build():
     if not os.path.exists(LIB):
+        return True
+    try:
+        if open(FLAGS_FILE).read() != " ".join(FLAGS):
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "dartk.h"), __file__]
@@ -45,6 +53,8 @@ def build(force=False, verbose=True):
     if failed:
         raise RuntimeError("libdartk build failed")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    with open(FLAGS_FILE, "w") as f:
+        f.write(" ".join(FLAGS))
     return LIB
 
 

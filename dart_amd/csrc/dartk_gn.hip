@@ -366,6 +366,172 @@ __device__ void ldlt_solve_wave64(float *A, int ld, int n, const float *b, float
     wave_sync();
 }
 
+// LDL^T with diagonal pivoting + solve for n <= NMAX = 32 by ONE wave with the matrix in REGISTERS: lane j owns column j
+// (c[i] = A[i][j]) and unknown j. Nothing is permuted: step k picks the not-yet-eliminated index p with the largest
+// |diagonal| (the pivot Eigen's ldlt() / the oracle pick, ties to the lowest index), every open lane turns its entry of row p
+// into L[j][p] (kept in c[p]) and subtracts (L[i][p]*d_p)*L[j][p] from its open rows, L[i][p]*d_p coming from lane i by
+// v_readlane. A single wave issues one instruction every four cycles whatever it is, so the step is written to be short
+// (no LDS round trips, ~3 instructions per open row) rather than wide. c[p] with the wave-uniform p is register-relative
+// addressing. The forward substitution runs on the same registers; the backward one needs L transposed (lane j: L[.][j]
+// of the rows eliminated after j), which goes once through LDS (T, row stride ldT).
+template <int NMAX>
+__device__ __forceinline__ float ldlt_solve_regs(float (&c)[NMAX], float dj, int n, float bj, float *T, int ldT, unsigned long long *stamps) {
+    const int lane = threadIdx.x & 63;
+    const bool mine = lane < n;
+    float dpiv = 0.0f;                                // pivot value once this index has been eliminated
+    int orderV = 0;                                   // lane k: index eliminated at step k
+    const unsigned long long all = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    unsigned long long todo = all;
+    // the forward substitution rides along: y_p is final when p is eliminated, and the open lanes subtract L[j][p]*y_p
+    // right away (the same terms in the same order as a separate pass in pivot order)
+    float yv = mine ? bj : 0.0f;
+    for (int k = 0; k < n; ++k) {
+        const bool open = mine && ((todo >> lane) & 1ull);
+        const unsigned key = open ? (__float_as_uint(fabsf(dj)) + 1u) : 0u;
+        const unsigned best = wave_max_u32(key);
+        const int p = __builtin_ctzll(__ballot(key == best));
+        const float dk = readlane_f(dj, p);
+        const float yp = readlane_f(yv, p);
+        if (lane == k) orderV = p;
+        if (lane == p) dpiv = dk;
+        todo &= ~(1ull << p);
+        if (dk == 0.0f) {                  // wave-uniform; the oracle / Eigen leave the column untouched
+            if (mine && ((todo >> lane) & 1ull)) yv = yv - c[p] * yp;
+            continue;
+        }
+        // branch-free rank-1 step: lanes that are not open any more carry l = 0, so their multiplier t = l*d_p is 0 and
+        // the rows they stand for (and row p, which keeps L[.][p]) are left as they are (x - 0*l == x for finite l; a
+        // non-finite factor is garbage in the branching formulation as well)
+        const bool rest = mine && ((todo >> lane) & 1ull);
+        const float cp = c[p];
+        const float lj = rest ? cp / dk : 0.0f;
+        c[p] = rest ? lj : cp;
+        dj = rest ? dj - (lj * dk) * lj : dj;
+        yv = rest ? yv - lj * yp : yv;
+        const float t = lj * dk;
+#pragma unroll
+        for (int i0 = 0; i0 < NMAX; i0 += 8) {
+            if (i0 < n) {
+#pragma unroll
+                for (int i = i0; i < i0 + 8; ++i) c[i] = c[i] - readlane_f(t, i) * lj;
+            }
+        }
+    }
+#ifdef DARTK_STAMPS
+    stamps[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    // D^-1 (Eigen's pseudo-inverse: tiny pivots give 0)
+    yv = (fabsf(dpiv) > 1.17549435e-38f) ? yv / dpiv : 0.0f;
+    // transpose L through LDS: T[i][j] = c[i] of lane j; lane j then holds r[p] = T[j][p] = L[p][j] for p eliminated after j
+    if (mine) {
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i)
+            if (i < n) T[i * ldT + lane] = c[i];
+    }
+    wave_sync();
+    float r[NMAX];
+#pragma unroll
+    for (int q = 0; q < NMAX; ++q) r[q] = (mine && q < n) ? T[lane * ldT + q] : 0.0f;
+    wave_sync();
+    // backward substitution with L^T: x_{p_k} = y_k - sum_{m>k} L[p_m][p_k] x_{p_m}
+    unsigned long long doneMask = 0ull;
+    for (int k = n - 1; k >= 0; --k) {
+        const int p = __builtin_amdgcn_readlane(orderV, k);
+        const float xp = readlane_f(yv, p);
+        doneMask |= (1ull << p);
+        if (mine && !((doneMask >> lane) & 1ull)) yv = yv - r[p] * xp;
+    }
+    return yv;
+}
+
+// entry (i, j) of the damped normal matrix: unpack (optimizer.cpp:50-70) in the reference's term order, symmetrise,
+// regularise, LM-scale
+__device__ __forceinline__ float assemble_entry(const SolveArgs &a, int d, int i, int j) {
+    const int ad = d - 6;
+    const int lo = i < j ? i : j, hi = i < j ? j : i;          // upper (lo,hi) <- packed[hi(hi+1)/2 + lo]
+    float v = 0.0f;
+    if (a.sysA) v += a.lambdaA * a.sysA[d + ((hi * (hi + 1)) >> 1) + lo];
+    if (a.sysB) v += a.lambdaB * a.sysB[d + ((hi * (hi + 1)) >> 1) + lo];
+    if (a.sysC && lo >= 6) {
+        const int p = lo - 6, q = hi - 6;
+        float t = 0.0f;
+        t += a.lambdaC * a.sysC[ad + ((q * (q + 1)) >> 1) + p];
+        v += t;
+    }
+    if (i == j) { v += a.regularization * 1.0f; v += a.lmLambda * v; }
+    return v;
+}
+__device__ __forceinline__ float assemble_rhs(const SolveArgs &a, int j) {
+    float v = 0.0f;
+    if (a.sysA) v += a.lambdaA * a.sysA[j];
+    if (a.sysB) v += a.lambdaB * a.sysB[j];
+    if (a.sysC && j >= 6) { float t = 0.0f; t += a.lambdaC * a.sysC[j - 6]; v += t; }
+    return v;
+}
+
+// d <= NMAX: the packed systems are combined into one packed system in LDS (coalesced reads; per entry the same sums in
+// the same order as assemble_entry), lane j then takes column j into registers and solves; returns x[j].
+// W: LDS scratch of at least max(sys_size(d), d * ldT) floats.
+template <int NMAX>
+__device__ __forceinline__ float assemble_solve_regs(const SolveArgs &a, int d, float *W, int ldT, unsigned long long *stamps) {
+    const int lane = threadIdx.x & 63;
+    const bool mine = lane < d;
+    const int j = mine ? lane : 0;
+    const int S = sys_size(d), ad = d - 6, Sa = sys_size(ad);
+    constexpr int NC = (sys_size(NMAX - 6) + 63) / 64;
+    float tc[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {      // the third system's loads go out with the first two
+        const int o = lane + 64 * q;
+        tc[q] = (a.sysC && o < Sa - 1) ? a.sysC[o] : 0.0f;
+    }
+    for (int o = lane; o < S - 1; o += 64) {
+        float v = 0.0f;
+        if (a.sysA) v += a.lambdaA * a.sysA[o];
+        if (a.sysB) v += a.lambdaB * a.sysB[o];
+        W[o] = v;
+    }
+    wave_sync();
+    if (a.sysC) {
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int o = lane + 64 * q;
+            if (o >= Sa - 1) continue;
+            float t = 0.0f;
+            t += a.lambdaC * tc[q];
+            int target;
+            if (o < ad) target = 6 + o;
+            else {
+                const int u = o - ad;
+                int q = (int)((sqrtf(8.0f * (float)u + 1.0f) - 1.0f) * 0.5f);
+                while (((q * (q + 1)) >> 1) > u) --q;
+                while ((((q + 1) * (q + 2)) >> 1) <= u) ++q;
+                const int p = u - ((q * (q + 1)) >> 1);
+                target = d + (((q + 6) * (q + 7)) >> 1) + p + 6;
+            }
+            W[target] += t;
+        }
+        wave_sync();
+    }
+    float c[NMAX];
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;          // upper (lo,hi) <- packed[hi(hi+1)/2 + lo]
+        c[i] = (i < d) ? W[d + ((hi * (hi + 1)) >> 1) + lo] : 0.0f;
+    }
+    float dj = c[0];
+#pragma unroll
+    for (int i = 1; i < NMAX; ++i) dj = (i == j) ? c[i] : dj;
+    dj += a.regularization * 1.0f;
+    dj += a.lmLambda * dj;
+    const float bj = W[j];
+    wave_sync();
+#ifdef DARTK_STAMPS
+    stamps[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    return ldlt_solve_regs<NMAX>(c, dj, d, bj, W, ldT, stamps);
+}
+
 // assemble + solve + update + forward kinematics (optimizer.cpp:482-518), ONE wave.
 __global__ void __launch_bounds__(64)
 gn_solve_single_kernel(ModelView m, SolveArgs a) {
@@ -390,29 +556,6 @@ gn_solve_single_kernel(ModelView m, SolveArgs a) {
         for (int o = tid; o < S; o += 64) { a.firstSystem[o] = sysA ? sysA[o] : 0.0f; a.firstSystem[S + o] = sysB ? sysB[o] : 0.0f; }
         for (int o = tid; o < Sa; o += 64) a.firstSystem[2 * S + o] = sysC ? sysC[o] : 0.0f;
     }
-    // unpack (optimizer.cpp:50-70) in the reference's term order, symmetrise, regularise, LM-scale
-    for (int idx = tid; idx < d * d; idx += 64) {
-        const int i = idx / d, j = idx % d;
-        const int lo = i < j ? i : j, hi = i < j ? j : i;          // upper (lo,hi) <- packed[hi(hi+1)/2 + lo]
-        float v = 0.0f;
-        if (sysA) v += a.lambdaA * sysA[d + ((hi * (hi + 1)) >> 1) + lo];
-        if (sysB) v += a.lambdaB * sysB[d + ((hi * (hi + 1)) >> 1) + lo];
-        if (sysC && lo >= 6) {
-            const int p = lo - 6, q = hi - 6;
-            float t = 0.0f;
-            t += a.lambdaC * sysC[ad + ((q * (q + 1)) >> 1) + p];
-            v += t;
-        }
-        if (i == j) { v += a.regularization * 1.0f; v += a.lmLambda * v; }
-        JTJ[i * ld + j] = v;
-    }
-    for (int j = tid; j < d; j += 64) {
-        float v = 0.0f;
-        if (sysA) v += a.lambdaA * sysA[j];
-        if (sysB) v += a.lambdaB * sysB[j];
-        if (sysC && j >= 6) { float t = 0.0f; t += a.lambdaC * sysC[j - 6]; v += t; }
-        eJ[j] = v;
-    }
     if (tid == 0) {
         if (a.iterInfo) {
             a.iterInfo[0] = sysA ? a.lambdaA * sysA[S - 1] : 0.0f;
@@ -424,12 +567,31 @@ gn_solve_single_kernel(ModelView m, SolveArgs a) {
         }
         *a.countA = 0; *a.countB = 0;       // ready for the next iteration's kernels (stream order)
     }
-    wave_sync();
 #ifdef DARTK_STAMPS
-    const unsigned long long st1 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st1 = st0, stF = 0;
 #endif
-    if (d <= 64) ldlt_solve_wave64(JTJ, ld, d, eJ, x, perm, y);
-    else ldlt_solve_wave(JTJ, ld, d, eJ, x, perm, y);
+    if (d <= 32) {
+        unsigned long long stamps[2] = {0, 0};
+        const float xj = assemble_solve_regs<32>(a, d, JTJ, ld, stamps);
+#ifdef DARTK_STAMPS
+        st1 = stamps[0]; stF = stamps[1];
+#endif
+        if (tid < d) x[tid] = xj;
+        wave_sync();
+    } else {
+        // unpack (optimizer.cpp:50-70) in the reference's term order, symmetrise, regularise, LM-scale
+        for (int idx = tid; idx < d * d; idx += 64) {
+            const int i = idx / d, j = idx % d;
+            JTJ[i * ld + j] = assemble_entry(a, d, i, j);
+        }
+        for (int j = tid; j < d; j += 64) eJ[j] = assemble_rhs(a, j);
+        wave_sync();
+#ifdef DARTK_STAMPS
+        st1 = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (d <= 64) ldlt_solve_wave64(JTJ, ld, d, eJ, x, perm, y);
+        else ldlt_solve_wave(JTJ, ld, d, eJ, x, perm, y);
+    }
 #ifdef DARTK_STAMPS
     const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -452,7 +614,7 @@ gn_solve_single_kernel(ModelView m, SolveArgs a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
     if (tid == 0 && a.iterInfo) {   // diagnostic build only: 10 ns ticks of assemble / LDL^T / update+FK in the spare slots
-        a.iterInfo[5] = (float)(st1 - st0); a.iterInfo[6] = (float)(st2 - st1); a.iterInfo[7] = (float)(st3 - st2);
+        a.iterInfo[5] = (float)(st1 - st0); a.iterInfo[6] = (float)(st2 - st1); a.iterInfo[7] = stF ? (float)(stF - st1) : (float)(st3 - st2);
     }
 #endif
 }

@@ -17,8 +17,8 @@ namespace dartk {
 
 #ifdef __HIPCC__
 
-__host__ __device__ inline int jtj_size(int d) { return (d * (d + 1)) >> 1; }
-__host__ __device__ inline int sys_size(int d) { return d + jtj_size(d) + 1; }
+__host__ __device__ constexpr int jtj_size(int d) { return (d * (d + 1)) >> 1; }
+__host__ __device__ constexpr int sys_size(int d) { return d + jtj_size(d) + 1; }
 // LDS row length (floats), padded to an odd stride so that consecutive rows start on different banks
 __host__ __device__ inline int row_len(int d, bool drop) {
     int n = (drop ? 2 * d + 3 : d + 3);
