@@ -14,7 +14,8 @@
 
 namespace dartk {
 
-static constexpr int GN_MAX_BLOCKS = 256;     // one partial system per CU at most: the solve kernel sums them
+static constexpr int GN_REDUCE_SEGS = 16;     // slab segments summed in parallel by gn_reduce_kernel, then added in a fixed order
+static constexpr int GN_MAX_BLOCKS = 1024;    // partial systems per term at most (the reduction kernel sums them)
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg) -------
 struct ProfEvent { int cls; hipEvent_t a, b; };
@@ -179,9 +180,9 @@ struct ReduceArgs { ReduceTerm t[4]; };
 // Fixed-order fp64 sum of the partial systems, spread over the chip: workgroup (x, term) owns 64 outputs of one
 // term; its 4 waves each sum a quarter of the slabs and the quarters are combined in a fixed order. Bitwise
 // reproducible (no atomics), ~1/4 MB read by ~15 workgroups instead of by one.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * GN_REDUCE_SEGS)
 gn_reduce_kernel(ReduceArgs a) {
-    __shared__ double part[4][64];
+    __shared__ double part[GN_REDUCE_SEGS][64];
     const ReduceTerm t = a.t[blockIdx.y];
     const int o = blockIdx.x * 64 + (threadIdx.x & 63);
     const int q = threadIdx.x >> 6;
@@ -190,7 +191,7 @@ gn_reduce_kernel(ReduceArgs a) {
     const int nBlocks = t.nItems ? min(t.nBlocks, (*t.nItems + t.itemsPerBlock - 1) / t.itemsPerBlock) : t.nBlocks;
     double s = 0.0;
     if (keep && o < t.S) {
-        const int per = (nBlocks + 3) >> 2;
+        const int per = (nBlocks + GN_REDUCE_SEGS - 1) / GN_REDUCE_SEGS;
         const int b0 = q * per, b1 = min(nBlocks, b0 + per);
         const float *p = t.slabs + (size_t)b0 * t.S + o;
         int b = b0;
@@ -206,7 +207,12 @@ gn_reduce_kernel(ReduceArgs a) {
     }
     part[q][threadIdx.x & 63] = s;
     __syncthreads();
-    if (q == 0 && o < t.S) t.out[o] = (float)(((part[0][o & 63] + part[1][o & 63]) + part[2][o & 63]) + part[3][o & 63]);
+    if (q == 0 && o < t.S) {        // fixed order
+        double tot = part[0][o & 63];
+#pragma unroll
+        for (int k = 1; k < GN_REDUCE_SEGS; ++k) tot += part[k][o & 63];
+        t.out[o] = (float)tot;
+    }
 }
 
 struct SolveArgs {
@@ -732,16 +738,9 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
             DARTK_HIP(hipStreamWaitEvent(stB, ws->evFork, 0));
         }
         if (useB) {
-            {
-                rc = gn_launch_raycast(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2),
-                                       o->predWidth, o->predHeight, 0, m, d_prediction, stB);
-                if (rc) return rc;
-            }
-            {
-                ProfScope ps(DARTK_PROF_NE_MOD2OBS, stB);
-                rc = gn_launch_ne_mod2obs(d_prediction, o->predWidth, o->predHeight, m, d_T_gc, slabsB, nBlocksB, cntB, stB);
-                if (rc) return rc;
-            }
+            rc = gn_launch_raycast_ne_mod2obs(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2),
+                                              o->predWidth, o->predHeight, 0, m, d_prediction, d_T_gc, slabsB, nBlocksB, cntB, stB);
+            if (rc) return rc;
             if (fork) DARTK_HIP(hipEventRecord(ws->evJoin, stB));
         }
         if (useA) {
@@ -783,7 +782,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         a.firstSystem = (it == 0) ? d_firstSystem : nullptr;
         if (nTerms) {
             ProfScope ps(DARTK_PROF_REDUCE, st);
-            hipLaunchKernelGGL(gn_reduce_kernel, dim3((S + 63) / 64, nTerms), dim3(256), 0, st, ra);
+            hipLaunchKernelGGL(gn_reduce_kernel, dim3((S + 63) / 64, nTerms), dim3(64 * GN_REDUCE_SEGS), 0, st, ra);
         }
         {
             ProfScope ps(DARTK_PROF_SOLVE, st);

@@ -19,6 +19,10 @@ namespace dartk {
 // identical to the serial walk; what is given up is the reference's pruning of traces behind the closest hit.
 // -----------------------------------------------------------------------------------------------------
 struct RayGeom { f3 of, dn; };
+#ifdef DARTK_STAMPS
+__device__ int g_rayMaxSteps;                    // diagnostic build only: longest march, total steps, marched rays
+__device__ unsigned long long g_raySteps, g_rayMarched;
+#endif
 
 // ray of pixel (x,y) expressed in the frame of an SDF whose camera->frame transform is T_fc (raycast.cu:147-161)
 __device__ __forceinline__ RayGeom ray_in_frame(const float *T_fc, int x, int y, float flx, float fly, float ppx, float ppy) {
@@ -73,7 +77,36 @@ raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int 
         t1 = fminf(fminf(fmaxf(tx, bx), fmaxf(ty, by)), fmaxf(tz, bz));
     }
     float det = 3.0e38f, hit = 0.0f;
-    if (t1 > t0) {
+    bool march = t1 > t0;
+    // A crossing needs a sample with value <= levelSet, i.e. a sample inside the SDF's keep box for that level (SdfDev;
+    // samples are clamped to [1, dim-2], so a box side that reaches the clamp planes extends to infinity): a ray that
+    // misses the box is not marched at all -- it could only have ended with "no crossing". Most rays of a tile miss the
+    // few-centimetre link inside its 10 cm padding.
+    const int slot = (levelSet <= 0.0f) ? 0 : keep_slot(levelSet);
+    if (march && slot >= 0) {
+        const float g0[3] = {(of.x - sdf.ox) / sdf.res, (of.y - sdf.oy) / sdf.res, (of.z - sdf.oz) / sdf.res};
+        const float gd[3] = {dn.x / sdf.res, dn.y / sdf.res, dn.z / sdf.res};
+        const float top[3] = {hix, hiy, hiz};
+        float tin = -3.0e38f, tout = 3.0e38f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = sdf.keepLo[slot][a], hi = sdf.keepHi[slot][a];
+            if (!(lo <= hi)) { tin = 1.0f; tout = 0.0f; break; }        // nothing at or below the level in this SDF
+            const bool openLo = lo <= 1.0f, openHi = hi >= top[a];
+            const float inv = 1.0f / gd[a];
+            float ta = ((lo - 0.05f) - g0[a]) * inv, tb = ((hi + 0.05f) - g0[a]) * inv;
+            if (openLo) ta = (gd[a] > 0) ? -3.0e38f : 3.0e38f;
+            if (openHi) tb = (gd[a] > 0) ? 3.0e38f : -3.0e38f;
+            if (gd[a] == 0.0f) {                                            // parallel to the slab: inside or never
+                const bool inside = (openLo || g0[a] >= lo - 0.05f) && (openHi || g0[a] <= hi + 0.05f);
+                ta = inside ? -3.0e38f : 3.0e38f; tb = inside ? 3.0e38f : -3.0e38f;
+            }
+            tin = fmaxf(tin, fminf(ta, tb));
+            tout = fminf(tout, fmaxf(ta, tb));
+        }
+        march = tin <= tout;
+    }
+    if (march) {
         const float *data = m.grids + sdf.dataOff;
         auto eval = [&](float tt) -> float {
             f3 xf, xg;
@@ -85,6 +118,9 @@ raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int 
         };
         float sdfValPrev = eval(t0);
         float tPrev = t0;
+#ifdef DARTK_STAMPS
+        int steps = 0;
+#endif
         const float minStep = sdf.res / 10;
         while (t0 < t1 && t0 < 10000.0f) {      // 10000 = the reference's initial closestT
             const float sdfVal = eval(t0);
@@ -96,12 +132,52 @@ raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int 
             sdfValPrev = sdfVal;
             tPrev = t0;
             t0 += fmaxf(minStep, fabsf(sdfVal));
+#ifdef DARTK_STAMPS
+            ++steps;
+#endif
         }
+#ifdef DARTK_STAMPS
+        atomicMax(&g_rayMaxSteps, steps);
+        atomicAdd(&g_raySteps, (unsigned long long)steps);
+        atomicAdd(&g_rayMarched, 1ull);
+#endif
     }
     trace[(size_t)s * width * height + (x + y * width)] = make_float2(det, hit);
 }
 
 static constexpr int RC_REPLAY_SDFS = 64;    // per-SDF transforms staged in LDS, this many at a time
+
+// camera->frame and frame->camera transforms of SDFs [s0, s0+nc) into sT (24 floats each); threads < nc work
+__device__ __forceinline__ void replay_stage_transforms(const ModelView &m, int s0, int nc, float *sT) {
+    if ((int)threadIdx.x < nc) {
+        const int f = m.sdfFrame[s0 + threadIdx.x];
+        float T_fm[12], T_mf[12], T_mc[12], T_cm[12], T_fc[12], T_cf[12];
+        for (int i = 0; i < 12; ++i) { T_fm[i] = m.T_fm[12 * f + i]; T_mf[i] = m.T_mf[12 * f + i]; T_mc[i] = m.T_mc[i]; }
+        se3_invert(T_mc, T_cm);                 // raycast.cu:143
+        se3_mul(T_fm, T_mc, T_fc);
+        se3_mul(T_cm, T_mf, T_cf);              // T_cm*T_mfs[f]
+        for (int i = 0; i < 12; ++i) { sT[24 * threadIdx.x + i] = T_fc[i]; sT[24 * threadIdx.x + 12 + i] = T_cf[i]; }
+    }
+}
+
+// the reference's sequential rule over SDFs [s0, s0+nc) for one pixel: a crossing counts iff it was detected before the
+// closest hit so far
+__device__ __forceinline__ void replay_pixel(float4 &pr, float &closestT, int x, int y, int index, int nPix, int modelNum, int s0, int nc,
+                                             const float *sT, const float2 *__restrict__ trace, float flx, float fly, float ppx, float ppy) {
+    for (int k = 0; k < nc; ++k) {
+        const float2 dh = trace[(size_t)(s0 + k) * nPix + index];
+        if (dh.x < closestT) {
+            const float tHit = dh.y;
+            const RayGeom g = ray_in_frame(sT + 24 * k, x, y, flx, fly, ppx, ppy);
+            const f3 xc = se3_apply_w(sT + 24 * k + 12, g.dn.x * tHit + g.of.x, g.dn.y * tHit + g.of.y, g.dn.z * tHit + g.of.z, 1.0f);
+            if (pr.z == 0 || xc.z < pr.z) {
+                pr.x = xc.x; pr.y = xc.y; pr.z = xc.z; pr.w = (float)((modelNum << 16) + s0 + k);
+            }
+            closestT = tHit;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 raycast_replay_kernel(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, ModelView m,
                       const float2 *__restrict__ trace, float4 *__restrict__ prediction) {
@@ -119,31 +195,26 @@ raycast_replay_kernel(float flx, float fly, float ppx, float ppy, int width, int
     for (int s0 = 0; s0 < m.nSdfs; s0 += RC_REPLAY_SDFS) {
         const int nc = min(RC_REPLAY_SDFS, m.nSdfs - s0);
         __syncthreads();
-        if ((int)threadIdx.x < nc) {
-            const int f = m.sdfFrame[s0 + threadIdx.x];
-            float T_fm[12], T_mf[12], T_mc[12], T_cm[12], T_fc[12], T_cf[12];
-            for (int i = 0; i < 12; ++i) { T_fm[i] = m.T_fm[12 * f + i]; T_mf[i] = m.T_mf[12 * f + i]; T_mc[i] = m.T_mc[i]; }
-            se3_invert(T_mc, T_cm);                 // raycast.cu:143
-            se3_mul(T_fm, T_mc, T_fc);
-            se3_mul(T_cm, T_mf, T_cf);              // T_cm*T_mfs[f]
-            for (int i = 0; i < 12; ++i) { sT[24 * threadIdx.x + i] = T_fc[i]; sT[24 * threadIdx.x + 12 + i] = T_cf[i]; }
-        }
+        replay_stage_transforms(m, s0, nc, sT);
         __syncthreads();
-        if (!valid) continue;
-        for (int k = 0; k < nc; ++k) {
-            const float2 dh = trace[(size_t)(s0 + k) * nPix + index];
-            if (dh.x < closestT) {
-                const float tHit = dh.y;
-                const RayGeom g = ray_in_frame(sT + 24 * k, x, y, flx, fly, ppx, ppy);
-                const f3 xc = se3_apply_w(sT + 24 * k + 12, g.dn.x * tHit + g.of.x, g.dn.y * tHit + g.of.y, g.dn.z * tHit + g.of.z, 1.0f);
-                if (pr.z == 0 || xc.z < pr.z) {
-                    pr.x = xc.x; pr.y = xc.y; pr.z = xc.z; pr.w = (float)((modelNum << 16) + s0 + k);
-                }
-                closestT = tHit;
-            }
-        }
+        if (valid) replay_pixel(pr, closestT, x, y, index, nPix, modelNum, s0, nc, sT, trace, flx, fly, ppx, ppy);
     }
     if (valid) prediction[index] = pr;
+}
+
+// the trace alone (the replay is done by the consumer: ne_mod2obs_kernel<.., REPLAY = true>)
+static int launch_raycast_trace(float flx, float fly, float ppx, float ppy, int width, int height, const ModelView &m, float levelSet,
+                                Workspace *ws, hipStream_t st) {
+    const size_t nPix = (size_t)width * height;
+    int rc = ensure_ray_buf(ws, 2 * nPix * (size_t)m.nSdfs);
+    if (rc) return rc;
+    const long long tasks = (long long)((width + 7) / 8) * ((height + 7) / 8) * m.nSdfs;
+    DARTK_REQUIRE(tasks < (1ll << 31), "ray-cast of %dx%d against %d SDFs exceeds the launch limits", width, height, m.nSdfs);
+    ProfScope ps(DARTK_PROF_RAYCAST, st);
+    hipLaunchKernelGGL(raycast_trace_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height, m,
+                       (float2 *)ws->rayBuf, levelSet);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
 }
 
 static int launch_raycast(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
@@ -151,16 +222,9 @@ static int launch_raycast(float flx, float fly, float ppx, float ppy, int width,
     Workspace *ws;
     int rc = get_workspace(&ws);
     if (rc) return rc;
-    const size_t nPix = (size_t)width * height;
-    rc = ensure_ray_buf(ws, 2 * nPix * (size_t)m.nSdfs);
+    rc = launch_raycast_trace(flx, fly, ppx, ppy, width, height, m, levelSet, ws, st);
     if (rc) return rc;
-    const long long tasks = (long long)((width + 7) / 8) * ((height + 7) / 8) * m.nSdfs;
-    DARTK_REQUIRE(tasks < (1ll << 31), "ray-cast of %dx%d against %d SDFs exceeds the launch limits", width, height, m.nSdfs);
-    {
-        ProfScope ps(DARTK_PROF_RAYCAST, st);
-        hipLaunchKernelGGL(raycast_trace_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height, m,
-                           (float2 *)ws->rayBuf, levelSet);
-    }
+    const size_t nPix = (size_t)width * height;
     ProfScope ps2(DARTK_PROF_RAYCAST_REPLAY, st);
     hipLaunchKernelGGL(raycast_replay_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height,
                        modelNum, m, (const float2 *)ws->rayBuf, (float4 *)d_prediction);
@@ -311,11 +375,18 @@ __global__ void dt_combine_kernel(float *__restrict__ im, const float *__restric
 // are compacted (deterministically) into LDS rows before the pair reduction, so empty image regions cost one
 // ballot. RED: 0 full, 1 linear, 2 param map. TRUNC: truncation window (modToObs.cu:163-166).
 // -----------------------------------------------------------------------------------------------------
-template <int PPT, int RED, bool TRUNC>
+struct ReplayArgs {            // REPLAY variant: the prediction is formed in the kernel from the ray-cast traces
+    float flx, fly, ppx, ppy;
+    int width, modelNum;       // modelNum: the label's model number (raycast.cu's modelNum argument)
+    const float2 *trace;       // [nSdfs][nPix] {detection t, hit t}
+    float4 *predOut;
+};
+
+template <int PPT, int RED, bool TRUNC, bool REPLAY = false>
 __global__ void __launch_bounds__(NE_BLOCK)
 ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, ModelView m, const float *__restrict__ T_gc_in,
                   float truncationDist, int redDims, const float *__restrict__ dtheta_dalpha, const int *__restrict__ mapping,
-                  float *__restrict__ slabs, int *__restrict__ numPredictions) {
+                  float *__restrict__ slabs, int *__restrict__ numPredictions, ReplayArgs ra) {
     extern __shared__ float lds[];
     const int fullDims = 6 + m.nJoints;
     const int d = RED ? redDims : fullDims;
@@ -326,7 +397,9 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
     float *sFull = sT_mf + 12 * m.nFrames;
     float *rows = sFull + (RED ? NE_BLOCK * fullLd : 0);
     int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ld);
+    float *sRT = reinterpret_cast<float *>(waveCnt + 8);       // REPLAY: per-SDF ray transforms, 24 * nSdfs floats
     stage_model(m, sT_fm, sT_mf, nullptr);
+    if (REPLAY) replay_stage_transforms(m, 0, m.nSdfs, sRT);    // nSdfs <= NE_BLOCK checked by the launcher
     float T_gc[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T_gc[i] = T_gc_in[i];
@@ -344,7 +417,17 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
         float residual = 0.0f;
         int frame = 0;
         if (index < nPix) {
-            const float4 pc = pred[index];
+            float4 pc;
+            if (REPLAY) {       // the pixel's prediction is formed here from the per-SDF traces and kept for the caller
+                pc = ra.predOut[index];
+                if (ra.modelNum == 0) { pc.z = 0; pc.w = -1; }
+                float closestT = 10000;
+                replay_pixel(pc, closestT, index % ra.width, index / ra.width, index, nPix, ra.modelNum, 0, m.nSdfs, sRT, ra.trace,
+                             ra.flx, ra.fly, ra.ppx, ra.ppy);
+                ra.predOut[index] = pc;
+            } else {
+                pc = pred[index];
+            }
             if (pc.z != 0) {
                 f3 p3; p3.x = pc.x; p3.y = pc.y; p3.z = pc.z;
                 pm = se3_apply(T_gc, p3);
@@ -408,7 +491,7 @@ static int launch_ne_mod2obs_kernel(int fullDims, int redDims, const float *d_pr
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
         hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, pred, nPix, m.modelId, m, d_T_gc, trunc,     \
-                           redDims, d_A, d_map, slabs, d_num);                                                  \
+                           redDims, d_A, d_map, slabs, d_num, ReplayArgs{});                                    \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_M2O(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_M2O(6);
@@ -453,6 +536,41 @@ int gn_launch_ne_mod2obs(const float *d_pred, int width, int height, const Model
 int gn_launch_raycast(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                       float *d_prediction, hipStream_t st) {
     return launch_raycast(flx, fly, ppx, ppy, width, height, modelNum, m, d_prediction, 0.0f, st);
+}
+// ray-cast + mod->obs normal equations of the same prediction: the trace kernel, then ONE kernel that replays each pixel's
+// traces (writing the prediction for the caller) and goes on with the pixel -- one launch less on the critical path
+int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
+                                 float *d_prediction, const float *d_T_gc, float *slabs, int nBlocks, int *d_num, hipStream_t st) {
+    if (m.nSdfs > NE_BLOCK) {
+        int rc = launch_raycast(flx, fly, ppx, ppy, width, height, modelNum, m, d_prediction, 0.0f, st);
+        if (rc) return rc;
+        ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
+        return gn_launch_ne_mod2obs(d_prediction, width, height, m, d_T_gc, slabs, nBlocks, d_num, st);
+    }
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    rc = launch_raycast_trace(flx, fly, ppx, ppy, width, height, m, 0.0f, ws, st);
+    if (rc) return rc;
+    const int d = 6 + m.nJoints, S = sys_size(d), nPix = width * height;
+    const size_t ldsBytes = ne_mod2obs_lds_bytes(m, d, 0) + sizeof(float) * 24 * (size_t)m.nSdfs;
+    DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
+    const ReplayArgs ra = {flx, fly, ppx, ppy, width, modelNum, (const float2 *)ws->rayBuf, (float4 *)d_prediction};
+    ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
+#define DARTK_LAUNCH_RM2O(PPT_)                                                                                 \
+    do {                                                                                                        \
+        auto kfn = ne_mod2obs_kernel<PPT_, 0, false, true>;                                                     \
+        if (ldsBytes > 64 * 1024)                                                                               \
+            DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_prediction, nPix, m.modelId, m, d_T_gc, 0.f, \
+                           d, nullptr, nullptr, slabs, d_num, ra);                                              \
+    } while (0)
+    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_RM2O(3);
+    else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_RM2O(6);
+    else DARTK_LAUNCH_RM2O(20);
+#undef DARTK_LAUNCH_RM2O
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
 }
 int gn_launch_cull(float *d_pred, int pw, int ph, const float *d_obs, int ow, int oh, hipStream_t st) {
     hipLaunchKernelGGL(cull_unobservable_kernel, dim3((pw * ph + 255) / 256), dim3(256), 0, st, (float4 *)d_pred, pw, ph,
@@ -500,6 +618,22 @@ error_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, ModelView m, dou
 using namespace dartk;
 
 extern "C" {
+
+#ifdef DARTK_STAMPS
+int dartk_debug_ray_steps(long long *out3) {
+    int mx = 0; unsigned long long st = 0, n = 0;
+    DARTK_HIP(hipDeviceSynchronize());
+    DARTK_HIP(hipMemcpyFromSymbol(&mx, HIP_SYMBOL(g_rayMaxSteps), sizeof(mx)));
+    DARTK_HIP(hipMemcpyFromSymbol(&st, HIP_SYMBOL(g_raySteps), sizeof(st)));
+    DARTK_HIP(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_rayMarched), sizeof(n)));
+    out3[0] = mx; out3[1] = (long long)st; out3[2] = (long long)n;
+    const int z = 0; const unsigned long long zz = 0;
+    DARTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rayMaxSteps), &z, sizeof(z)));
+    DARTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_raySteps), &zz, sizeof(zz)));
+    DARTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rayMarched), &zz, sizeof(zz)));
+    return DARTK_OK;
+}
+#endif
 
 int dartk_raycast_prediction(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum,
                              dartk_model_t h, float *d_prediction, float levelSet, void *stream) {

@@ -16,3 +16,14 @@ for _ in range(3):
 torch.cuda.synchronize()
 print("stamps (us) assemble / ldlt / update+fk per iteration:")
 print(opt.iter_info.cpu().numpy()[:, 5:8] / 100.0)
+import ctypes
+from dart_amd import _abi
+buf = (ctypes.c_longlong * 3)()
+fn = getattr(_abi.lib(), "dartk_debug_ray_steps", None)
+if fn is not None:
+    fn(buf)
+    dm.set_pose(sc.init_T_mc, sc.init_joints)
+    opt.optimizePose(dm, vert, norm, sc.opts)
+    fn(buf)
+    n_it = sc.opts.numIterations
+    print("ray-cast per iteration: longest march %d steps, %.0f marched rays, %.1f steps/ray" % (buf[0], buf[2] / n_it, buf[1] / max(buf[2], 1)))
