@@ -35,8 +35,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0
 PROF_NAMES = ["obs_sdf_build", "raycast_trace_kernel", "fused_obs2mod_kernel", "ne_mod2obs_kernel", "ne_self_intersection_kernel",
-              "gn_solve_single_kernel", "raycast_replay_kernel", "valid_pixel_compaction", "gn_reduce_kernel", "noobs_terms_kernel",
-              "noobs_solve_kernel", "unused"]
+              "gn_solve_single_kernel", "raycast_replay_kernel", "valid_pixel_compaction", "gn_reduce_kernel",
+              "noobs_terms_kernel<intersection>", "noobs_solve_kernel", "noobs_terms_kernel<priors>"]
 O_ASSOC, O_ASSOC_GRAD, O_NE_O2M, O_RAYCAST, O_M2O, O_INTER, O_PRIOR = 1, 2, 3, 4, 5, 6, 7
 N_CLASSES = 12
 # PMC HBM traffic per launch (bytes) measured with rocprofv3 --pmc, corrected as MI355X_MICROARCH.md prescribes; filled in
@@ -61,7 +61,8 @@ def prof_collect(lib, fptr, iptr, check, fn, reps):
 
 
 def tr_slab_floats(tr):
-    """floats of partial systems one candidate writes per terms-kernel launch (for the algorithmic-bytes figure)."""
+    """floats of partial systems one candidate writes per pass of the term kernels (for the algorithmic-bytes figure):
+    (intersection terms, contact-prior term)."""
     D_ = sum(m.dims for m in tr.models)
 
     def S(d):
@@ -79,8 +80,7 @@ def tr_slab_floats(tr):
             if d != m and lam[m + d * n] > 0:
                 total += blocks * S(tr.models[m].dims)
     tiles = (len(tr.priors) + 127) // 128
-    total += (min(tiles, 4) if many else tiles) * S(D_)
-    return total
+    return total, (min(tiles, 4) if many else tiles) * S(D_)
 
 
 def main():
@@ -193,10 +193,10 @@ def main():
                                     + 32.0 * st[O_ASSOC_GRAD] / iters + 4.0 * S * ((n_valid + 127) // 128),
             # 32 B per marching-step lookup (the reference's pruned count) + 8 B trace record per (pixel, SDF)
             "raycast_trace_kernel": 32.0 * st[O_RAYCAST] / iters + 8.0 * P * n_sdfs,
-            "raycast_replay_kernel": 8.0 * P * n_sdfs + 32.0 * P,
-            # 16 B per prediction pixel + 32 B per lookup (value + gradient) + partial systems
-            "ne_mod2obs_kernel": 16.0 * P + 32.0 * st[O_M2O] / iters + 4.0 * S * 256,
-            "gn_reduce_kernel": 4.0 * S * (256 + (n_valid + 127) // 128) + 8.0 * S,
+            # (the replay of the traces is part of this kernel) 8 B trace record per (pixel, SDF) + prediction read and
+            # write + 32 B per lookup (value + gradient) + one partial system per 128-pixel tile
+            "ne_mod2obs_kernel": 8.0 * P * n_sdfs + 32.0 * P + 32.0 * st[O_M2O] / iters + 4.0 * S * min((P + 127) // 128, 1024),
+            "gn_reduce_kernel": 4.0 * S * (min((P + 127) // 128, 1024) + (n_valid + 127) // 128) + 8.0 * S,
             "gn_solve_single_kernel": 4.0 * 2 * S + 96.0 * 17 * 2,
             "obs_sdf_build": 4.0 * 64 ** 3 * 9 + 16.0 * 64 ** 3,
         }
@@ -269,12 +269,18 @@ def main():
             O.lib().orc_stats_enable(0)
             st = (C.c_longlong * 8)()
             O.lib().orc_stats_get(st)
-            lookups = (st[O_INTER] + st[O_PRIOR]) / len(sample)
+            lk_inter, lk_prior = st[O_INTER] / len(sample), st[O_PRIOR] / len(sample)
             Q = len(gs.priors)
             Cn = sum(len(c) for c in clouds) + len(clouds[0])      # the hand cloud is walked twice (self + object)
-            per_cand = 24.0 * Q + 16.0 * Cn + 32.0 * lookups + 4.0 * tr_slab_floats(tr)
-            bpl = per_cand * len(idx)
-            us = per_launch_us["noobs_terms_kernel"]
+            slab_inter, slab_prior = tr_slab_floats(tr)
+            K_I, K_P = "noobs_terms_kernel<intersection>", "noobs_terms_kernel<priors>"
+            # per candidate and pass: 40 B per contact prior / 16 B per cloud point + 32 B per trilinear lookup + partial systems
+            bytes_per_launch = {K_P: (40.0 * Q + 32.0 * lk_prior + 4.0 * slab_prior) * len(idx),
+                                # three intersection kernels per pass: the figure is their sum over the class's launches
+                                K_I: (16.0 * Cn + 32.0 * lk_inter + 4.0 * slab_inter) * len(idx) / 3.0}
+            g_name = max((K_I, K_P), key=lambda k: per_step_us.get(k, 0.0))
+            bpl = bytes_per_launch[g_name]
+            us = per_launch_us[g_name]
             ach = bpl / (us * 1e-6) / 1e9
             g_cpu = None
             if not args.no_cpu_baseline:
@@ -299,11 +305,15 @@ def main():
                                              "intersection, %d iterations + getError, round-robin over %d GPU(s), one all-gather of "
                                              "{energy, pose}" % (n_cand, Q, g_iters, world)},
                       "best_candidates": [int(b) for b in best],
-                      "roofline": {"bound": "hbm", "kernel": "noobs_terms_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": PMC_TRAFFIC.get("noobs_terms_kernel"),
+                      "roofline": {"bound": "hbm", "kernel": g_name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": PMC_TRAFFIC.get(g_name),
                                    "algorithmic_bytes_per_launch": round(bpl), "avg_launch_us": round(us, 2),
                                    "per_step_us": {k: round(v, 2) for k, v in per_step_us.items()},
-                                   "lookups_per_candidate_per_iteration": lookups},
+                                   "per_kernel_achieved_GBs": {k: round(bytes_per_launch[k] / (per_launch_us[k] * 1e-6) / 1e9, 2)
+                                                               for k in bytes_per_launch if k in per_launch_us},
+                                   "lookups_per_candidate_per_iteration": {"intersection": lk_inter, "priors": lk_prior},
+                                   "note": "the term kernels are instruction-issue bound (sphere / box rejects and exact bound tests per "
+                                           "(point, SDF) pair), not bandwidth bound: see DESIGN.md"},
                       "cpu_baseline": g_cpu}
 
     if rank == 0:

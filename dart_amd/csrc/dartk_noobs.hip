@@ -547,9 +547,9 @@ static int noobs_launch_term_ppt(NoObs *t, int term, int batch, hipStream_t st) 
 
 // one launch per term (the terms write disjoint slabs; the solve kernel that follows reads them all)
 static int noobs_launch_terms(NoObs *t, int batch, hipStream_t st) {
-    ProfScope ps(DARTK_PROF_NOOBS_TERMS, st);
     for (int i = 0; i < t->h.nTerms; ++i) {
         int rc;
+        ProfScope ps(t->h.term[i].type == TERM_PRIORS ? DARTK_PROF_NOOBS_PRIORS : DARTK_PROF_NOOBS_TERMS, st);
         switch (t->h.term[i].type) {
         case TERM_SELF: rc = noobs_launch_term_ppt<TERM_SELF>(t, i, batch, st); break;
         case TERM_INTER: rc = noobs_launch_term_ppt<TERM_INTER>(t, i, batch, st); break;

@@ -272,7 +272,8 @@ int dartk_noobs_get_error(dartk_noobs_t t, const dartk_noobs_options *opts, int 
 enum dartk_prof_class {
     DARTK_PROF_OBS_SDF = 0, DARTK_PROF_RAYCAST = 1 /* trace kernel */, DARTK_PROF_FUSED_OBS2MOD = 2, DARTK_PROF_NE_MOD2OBS = 3,
     DARTK_PROF_NE_SELF = 4, DARTK_PROF_SOLVE = 5, DARTK_PROF_RAYCAST_REPLAY = 6, DARTK_PROF_OTHER = 7, DARTK_PROF_REDUCE = 8,
-    DARTK_PROF_NOOBS_TERMS = 9, DARTK_PROF_NOOBS_SOLVE = 10, DARTK_PROF_CLASSES = 12
+    DARTK_PROF_NOOBS_TERMS = 9 /* self- and pairwise intersection term kernels */, DARTK_PROF_NOOBS_SOLVE = 10,
+    DARTK_PROF_NOOBS_PRIORS = 11 /* contact-prior term kernel */, DARTK_PROF_CLASSES = 12
 };
 int dartk_profile_begin(void);
 int dartk_profile_end(float *h_ms_total /*[DARTK_PROF_CLASSES]*/, int32_t *h_launches /*[DARTK_PROF_CLASSES]*/);

@@ -25,21 +25,27 @@ def per_kernel(path, counter):
 
 def short(name):
     n = name.split("(")[0].replace("void ", "").replace("dartk::", "")
+    if n.startswith("noobs_terms_kernel<"):       # one instantiation per term type: keep them apart (bench.py's class names)
+        typ = n[n.index("<") + 1:n.index(">")].split(",")[-1].strip()
+        return "noobs_terms_kernel<priors>" if typ == "2" else "noobs_terms_kernel<intersection>"
     return n.split("<")[0]
 
 
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {}
+    out, launches = {}, {}
     print("%-40s %8s %16s %16s %18s" % ("kernel", "launches", "FETCH_KiB/launch", "WRITE_KiB/launch", "HBM_bytes/launch"))
     for k in sorted(fetch, key=lambda k: -fetch[k][0] * fetch[k][1]):
         f, n = fetch[k]
         w = write.get(k, (0.0, 0))[0]
         b = (2.0 * f + w) * 1024.0
         print("%-40s %8d %16.1f %16.1f %18.0f" % (short(k)[:40], n, f, w, b))
-        if "dartk::" in k:
-            out[short(k)] = round(b)
+        if "dartk::" in k:      # instantiations that share a name: launch-weighted mean
+            key = short(k)
+            out[key] = out.get(key, 0.0) + b * n
+            launches[key] = launches.get(key, 0) + n
+    out = {k: round(v / launches[k]) for k, v in out.items()}
     if len(sys.argv) > 3:
         json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 
