@@ -1,0 +1,84 @@
+"""CPU tests of ContactGrasp's file formats and of the point selection (dart_amd/grasp_analyzer.py)."""
+import json
+import os
+
+import numpy as np
+
+from dart_amd import grasp_analyzer as GA
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _fnv(idx):
+    h = 1469598103934665603
+    for v in idx:
+        h ^= v
+        h = (h * 1099511628211) % (1 << 64)
+    return str(h)
+
+
+def test_std_shuffle_matches_libstdcxx_golden():
+    """tests/golden/std_shuffle.json was produced by g++'s std::shuffle + std::default_random_engine (gen_std_shuffle.cpp):
+    two shuffles in a row with one engine, including list sizes on both sides of the two-swaps-per-draw switch."""
+    cases = json.load(open(os.path.join(HERE, "golden", "std_shuffle.json")))
+    assert len(cases) >= 5
+    for c in cases:
+        rng = GA.MinStdRand0()
+        a = GA.std_shuffle(list(range(c["sizes"][0])), rng)
+        b = GA.std_shuffle(list(range(c["sizes"][1])), rng)
+        assert a[:40] == c["first"] and _fnv(a) == c["hash0"], c["sizes"]
+        assert b[:40] == c["second"] and _fnv(b) == c["hash1"], c["sizes"]
+
+
+def test_grasp_csv_round_trip(tmp_path):
+    rng = np.random.default_rng(3)
+    T = rng.normal(size=(5, 12)).astype(np.float32)
+    J = rng.uniform(-1, 1, size=(5, 20)).astype(np.float32)
+    p = tmp_path / "obj_grasps.csv"
+    GA.write_grasps_csv(str(p), T, J)
+    T2, J2 = GA.read_grasps_csv(str(p), 20)
+    # operator<< prints 6 significant digits
+    np.testing.assert_allclose(T2, T, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(J2, J, rtol=1e-5, atol=1e-6)
+    # DOF mapping permutes where the file's values land (grasp_analyzer.cpp:146-150)
+    mapping = list(range(20))
+    mapping[0], mapping[1] = 1, 0
+    _, J3 = GA.read_grasps_csv(str(p), 20, mapping)
+    np.testing.assert_allclose(J3[:, 0], J[:, 1], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(J3[:, 1], J[:, 0], rtol=1e-5, atol=1e-6)
+
+
+def test_pose_string_gt_and_short_lines():
+    line = "7," + ",".join(str(i) for i in range(12 + 4))
+    T, j, gt = GA.pose_from_string(line, 4, read_gt=True)
+    assert gt == 7 and T[3] == 3 and list(j) == [12, 13, 14, 15]
+    assert GA.pose_from_string("1,2,3", 4) is None            # too few values: the reference leaves the pose alone
+    s = GA.string_from_pose(np.arange(12), [0.5, 0.25])
+    assert s == "0,1,2,3,4,5,6,7,8,9,10,11,0.5,0.25"
+
+
+def test_contact_info_and_errors(tmp_path):
+    p = tmp_path / "s_o_contact_info.txt"
+    p.write_text("1 1.15 0 0 0 0 1\n0 0 2.3 0 1 0 0\n\n1 0 0 -1.15 0 1 0\n")
+    cp, cn, ncp, ncn = GA.read_contact_info(str(p), scale=2.0)
+    np.testing.assert_allclose(cp, [[2.0, 0, 0], [0, 0, -2.0]], rtol=1e-6)
+    np.testing.assert_allclose(ncp, [[0, 4.0, 0]], rtol=1e-6)
+    assert cn.shape == (2, 3) and ncn.shape == (1, 3)
+    e = tmp_path / "errors.csv"
+    GA.write_grasp_errors(str(e), [[0.5, 2.0], [0.25, 1.0], [0.75]])
+    assert e.read_text() == "0.5,2\n0.25,1\n0.75\n"
+    col0 = GA.read_grasp_errors(str(e), 0, 4)
+    assert list(col0[:3]) == [0.5, 0.25, 0.75] and col0[3] == np.finfo(np.float32).max
+    th = tmp_path / "thumb.txt"
+    th.write_text("15 7.997e-3 4.979e-3 26.407e-3")
+    assert GA.read_thumb_file(str(th)) == (15, (7.997e-3, 4.979e-3, 26.407e-3))
+    pm = tmp_path / "pot.txt"
+    pm.write_text("0 1\n1 0\n")
+    assert list(GA.read_potential_matrix(str(pm), 2)) == [0, 1, 1, 0]
+
+
+def test_compare_poses():
+    a = np.zeros((2, 12), dtype=np.float32)
+    b = a.copy()
+    b[0, 3], b[1, 11] = 1.0, 2.0
+    assert GA.compare_poses(a, b) == 5.0
