@@ -47,6 +47,13 @@ class ContactPriorC(C.Structure):
                 ("updateContact", C.c_int32)]
 
 
+class PointPriorC(C.Structure):
+    """dartk_point_prior (include/dartk.h); orc_point_prior has the same layout."""
+    _fields_ = [("kind", C.c_int32), ("srcModel", C.c_int32), ("srcFrame", C.c_int32), ("weight", C.c_float),
+                ("point_f", C.c_float * 3), ("point_c", C.c_float * 3), ("focalLength", C.c_float * 2),
+                ("principalPoint", C.c_float * 2)]
+
+
 class NoObsOptions(C.Structure):
     """dartk_noobs_options (include/dartk.h); orc_noobs_options has the same layout."""
     _fields_ = [("numIterations", C.c_int32), ("nModels", C.c_int32), ("regularization", C.c_float * 8),
@@ -151,6 +158,7 @@ def lib():
                                C.POINTER(ContactPriorC), C.c_int, C.c_int, C.POINTER(vp)],
         "dartk_noobs_destroy": [vp],
         "dartk_noobs_set_priors": [vp, C.POINTER(ContactPriorC), C.c_int, vp],
+        "dartk_noobs_set_point_priors": [vp, C.POINTER(PointPriorC), C.c_int, vp],
         "dartk_noobs_optimize_poses": [vp, C.POINTER(NoObsOptions), C.c_int, vp, vp, vp, vp, vp, vp],
         "dartk_noobs_get_error": [vp, C.POINTER(NoObsOptions), C.c_int, vp, vp, vp, vp],
         "dartk_profile_begin": [],

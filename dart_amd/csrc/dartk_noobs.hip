@@ -21,8 +21,9 @@
 
 namespace dartk {
 
-enum { TERM_SELF = 0, TERM_INTER = 1, TERM_PRIORS = 2 };
-static constexpr int NOOBS_MAX_TERMS = DARTK_MAX_MODELS * DARTK_MAX_MODELS + 1;
+enum { TERM_SELF = 0, TERM_INTER = 1, TERM_PRIORS = 2, TERM_POINTS = 3 };
+__host__ __device__ constexpr bool term_weighted(int type) { return type == TERM_PRIORS || type == TERM_POINTS; }
+static constexpr int NOOBS_MAX_TERMS = DARTK_MAX_MODELS * DARTK_MAX_MODELS + 2;
 
 struct NoObsTerm {
     int type, src, dst;
@@ -46,6 +47,8 @@ struct NoObsProblem {            // device-visible description shared by both ke
     ModelView model[DARTK_MAX_MODELS];   // static tables only; pose pointers are rebased per candidate
     NoObsTerm term[NOOBS_MAX_TERMS];
     const dartk_contact_prior *priors;
+    const dartk_point_prior *pointPriors;     // Point3D3DPrior / Point2D3DPrior list, three rows each (TERM_POINTS)
+    int nPointPriors;
 };
 
 #ifdef DARTK_STAMPS
@@ -58,8 +61,8 @@ __device__ unsigned long long g_noobsStamps[3][8];
 
 // LDS row length of a term: the packed-system row, and at least the parked state of an active point (8 / 16 floats)
 __host__ __device__ inline int noobs_row_len(int type, int d) {
-    const int ld = tile_row_len(d, type == TERM_PRIORS);
-    const int need = type == TERM_PRIORS ? 16 : 8;
+    const int ld = tile_row_len(d, term_weighted(type));
+    const int need = term_weighted(type) ? 16 : 8;
     return ld > need ? ld : need;
 }
 
@@ -167,7 +170,8 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     TileAcc<NE_BLOCK, TPT> acc;
     acc.init(d);
     NOOBS_STAMP(1);
-    const int lOff = tile_l_off(d, TYPE == TERM_PRIORS);
+    constexpr bool WEIGHTED = term_weighted(TYPE);
+    const int lOff = tile_l_off(d, WEIGHTED);
     double errInactive = 0.0;       // contact priors: _error of priors that contribute no row
     // rows of the parked points [0, n): Jacobians by the first n threads, then every thread adds its packed entries
     auto flush = [&](int n) {
@@ -179,7 +183,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
             pm.x = row[0]; pm.y = row[1]; pm.z = row[2]; gs.x = row[3]; gs.y = row[4]; gs.z = row[5];
             const float residual = row[6];
             const int packed = __float_as_int(row[7]);
-            if constexpr (TYPE == TERM_PRIORS) {
+            if constexpr (WEIGHTED) {
                 // subJ = [ dot(grad_sm, J3D_src) | -dot(grad_dm, J3D_dst) ] placed at the models' global offsets (:110-126)
                 f3 pdm, gdm;
                 pdm.x = row[8]; pdm.y = row[9]; pdm.z = row[10]; gdm.x = row[11]; gdm.y = row[12]; gdm.z = row[13];
@@ -215,7 +219,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         }
         __syncthreads();
         NOOBS_STAMP(4);
-        if (n) acc.template accumulate<TYPE == TERM_PRIORS>(rows, ld, n, lOff);
+        if (n) acc.template accumulate<WEIGHTED>(rows, ld, n, lOff);
         __syncthreads();
         NOOBS_STAMP(5);
     };
@@ -260,6 +264,45 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                     gs = se3_rotate(sT_ds + 12, gd);
                     residual = col.residual;
                     active = true;
+                }
+            } else if constexpr (TYPE == TERM_POINTS) {
+                // Point3D3DPrior / Point2D3DPrior::computeContribution (point_3d_3d_prior.cpp:6-69, point_2d_3d_prior.cpp:6-83):
+                // row k of a prior's 3 (2) x dims Jacobian is dot(e_k, J3D) resp. dot(projection gradient, J3D); thread = (prior, k)
+                const int q = index / 3, comp = index - 3 * q;
+                const dartk_point_prior pr = P->pointPriors[q];
+                if (pr.weight != 0) {
+                    pSrc = pr.srcModel; srcFrame = pr.srcFrame;
+                    const ModelView ms = rebase(P->model[pSrc], poseC + P->poseOff[pSrc]);
+                    const float *smf = sTf(pSrc) + 12 * ms.nFrames + 12 * srcFrame;
+                    float T_cm[12], T_mf[12], T_fc[12];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) { T_cm[i] = ms.T_cm[i]; T_mf[i] = smf[i]; }
+                    se3_mul(T_cm, T_mf, T_fc);                       // MirroredModel::getTransformFrameToCamera
+                    const f3 pc = se3_apply_w(T_fc, pr.point_f[0], pr.point_f[1], pr.point_f[2], 1.0f);
+                    pm = se3_apply_w(smf, pr.point_f[0], pr.point_f[1], pr.point_f[2], 1.0f);
+                    if (pr.kind == 0) {
+                        f3 dc; dc.x = pc.x - pr.point_c[0]; dc.y = pc.y - pr.point_c[1]; dc.z = pc.z - pr.point_c[2];
+                        const float dist = sqrtf(dot(dc, dc));
+                        if (dist != 0) {
+                            const f3 dm = se3_rotate(ms.T_mc, dc);
+                            gs.x = comp == 0 ? 1.f : 0.f; gs.y = comp == 1 ? 1.f : 0.f; gs.z = comp == 2 ? 1.f : 0.f;
+                            residual = comp == 0 ? dm.x : (comp == 1 ? dm.y : dm.z);
+                            active = true;
+                        }
+                    } else if (comp < 2) {
+                        const float px = pc.x * pr.focalLength[0] / pc.z + pr.principalPoint[0];
+                        const float py = pc.y * pr.focalLength[1] / pc.z + pr.principalPoint[1];
+                        const float dx = px - pr.point_c[0], dy = py - pr.point_c[1];
+                        if (sqrtf(dx * dx + dy * dy) != 0) {
+                            f3 gc;       // d(pixel_k)/d(point_c); dot(g_c, R_cm J3D) == dot(R_mc g_c, J3D)
+                            if (comp == 0) { gc.x = pr.focalLength[0] / pc.z; gc.y = 0.f; gc.z = -(pc.x) * pr.focalLength[0] / (pc.z * pc.z); }
+                            else { gc.x = 0.f; gc.y = pr.focalLength[1] / pc.z; gc.z = -(pc.y) * pr.focalLength[1] / (pc.z * pc.z); }
+                            gs = se3_rotate(ms.T_mc, gc);
+                            residual = comp == 0 ? dx : dy;
+                            active = true;
+                        }
+                    }
+                    weight = pr.weight; upSrc = true; upDst = false; E = 0.0f;
                 }
             } else {
                 // ContactPrior::computeContribution, contact_prior.cpp:17-95
@@ -342,7 +385,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         if (active) {
             float *e = rows + (pending + slot) * ld;
             e[0] = pm.x; e[1] = pm.y; e[2] = pm.z; e[3] = gs.x; e[4] = gs.y; e[5] = gs.z; e[6] = residual;
-            if constexpr (TYPE == TERM_PRIORS) {
+            if constexpr (WEIGHTED) {
                 e[7] = __int_as_float(srcFrame | (dstFrame << 8) | (pSrc << 16) | (pDst << 20) | ((int)upSrc << 24) | ((int)upDst << 25));
                 e[8] = pdm.x; e[9] = pdm.y; e[10] = pdm.z; e[11] = gdm.x; e[12] = gdm.y; e[13] = gdm.z; e[14] = weight; e[15] = E;
             } else {
@@ -411,7 +454,7 @@ noobs_solve_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         for (int o = lane; o < T.S; o += 64) sys[o] = reduce_slot(slabC + T.slabOff, T.nBlocks, T.S, o);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int d = T.dims;
-        if (T.type == TERM_PRIORS) {
+        if (term_weighted(T.type)) {
             // priors add into the global upper triangle after the model blocks were scattered (:913-916)
             for (int idx = lane; idx < D * D; idx += 64) {
                 const int i = idx / D, j = idx - i * D;
@@ -420,7 +463,7 @@ noobs_solve_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                 if (v != 0) U[i * ld + j] += v;
             }
             for (int i = lane; i < D; i += 64) b[i] += sys[i];
-            ePri = sys[T.S - 1];
+            if (T.type == TERM_PRIORS) ePri = sys[T.S - 1];
         } else {
             const int m = T.src;
             const float lam = a.lambda[T.src + T.dst * nModels];
@@ -436,7 +479,8 @@ noobs_solve_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const float energy = eInt + (P->nPriors > 0 ? ePri / (float)P->nPriors : 0.0f);
+    const int nPriorsAll = P->nPriors + P->nPointPriors;     // pe / priors.size(), optimizer.cpp:1068
+    const float energy = eInt + (nPriorsAll > 0 ? ePri / (float)nPriorsAll : 0.0f);
     if (a.energyOnly) {
         if (lane == 0) a.energy[c] = energy;
         return;
@@ -515,8 +559,10 @@ struct NoObs {
     NoObsProblem h;            // host copy
     NoObsProblem *d;           // device copy
     dartk_contact_prior *d_priors;
+    dartk_point_prior *d_pointPriors;
     int nPriors;
     int maxBatch;
+    int ldsModels, slabFloats;     // LDS floats of the staged model tables; slab floats per candidate of the fixed terms
     float *poses, *slabs;
     int SMax, maxFrames, potLdsInts;
     size_t ldsTerm[NOOBS_MAX_TERMS], ldsSolve;
@@ -549,10 +595,11 @@ static int noobs_launch_term_ppt(NoObs *t, int term, int batch, hipStream_t st) 
 static int noobs_launch_terms(NoObs *t, int batch, hipStream_t st) {
     for (int i = 0; i < t->h.nTerms; ++i) {
         int rc;
-        ProfScope ps(t->h.term[i].type == TERM_PRIORS ? DARTK_PROF_NOOBS_PRIORS : DARTK_PROF_NOOBS_TERMS, st);
+        ProfScope ps(term_weighted(t->h.term[i].type) ? DARTK_PROF_NOOBS_PRIORS : DARTK_PROF_NOOBS_TERMS, st);
         switch (t->h.term[i].type) {
         case TERM_SELF: rc = noobs_launch_term_ppt<TERM_SELF>(t, i, batch, st); break;
         case TERM_INTER: rc = noobs_launch_term_ppt<TERM_INTER>(t, i, batch, st); break;
+        case TERM_POINTS: rc = noobs_launch_term_ppt<TERM_POINTS>(t, i, batch, st); break;
         default: rc = noobs_launch_term_ppt<TERM_PRIORS>(t, i, batch, st); break;
         }
         if (rc) return rc;
@@ -577,6 +624,7 @@ int dartk_noobs_destroy(dartk_noobs_t h) {
     if (!t) return DARTK_OK;
     if (t->d) (void)hipFree(t->d);
     if (t->d_priors) (void)hipFree(t->d_priors);
+    if (t->d_pointPriors) (void)hipFree(t->d_pointPriors);
     if (t->poses) (void)hipFree(t->poses);
     if (t->slabs) (void)hipFree(t->slabs);
     delete t;
@@ -655,6 +703,7 @@ int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *co
     if (nPriors > 0) add(TERM_PRIORS, 0, 0, nPriors, D, nullptr, nullptr);
     for (int i = 0; i < nModels * nModels; ++i) t->lambdaActive[i] = h_lambdaIntersection[i] > 0;
     P.nTerms = nTerms; P.slabStride = slabOff > 0 ? slabOff : 1;
+    t->ldsModels = ldsModels; t->slabFloats = slabOff;
     t->SMax = SMax; t->maxFrames = maxFrames; t->maxBatch = maxBatch; t->nPriors = nPriors;
     size_t ldsTermMax = 0;
     for (int i = 0; i < nTerms; ++i) if (t->ldsTerm[i] > ldsTermMax) ldsTermMax = t->ldsTerm[i];
@@ -691,6 +740,66 @@ int dartk_noobs_set_priors(dartk_noobs_t h, const dartk_contact_prior *h_priors,
         DARTK_HIP(hipMemcpyAsync(t->d_priors, h_priors, sizeof(dartk_contact_prior) * (size_t)nPriors, hipMemcpyHostToDevice, as_stream(stream)));
         DARTK_HIP(hipStreamSynchronize(as_stream(stream)));
     }
+    return DARTK_OK;
+}
+
+}  // extern "C" (reopened below)
+
+// the TERM_POINTS term is always the last one: drop it / append it, then re-size what depends on the term table
+static int noobs_set_points_term(NoObs *t, int n) {
+    NoObsProblem &P = t->h;
+    if (P.nTerms > 0 && P.term[P.nTerms - 1].type == TERM_POINTS) --P.nTerms;
+    int slabOff = t->slabFloats;
+    if (n > 0) {
+        NoObsTerm &T = P.term[P.nTerms];
+        T.type = TERM_POINTS; T.src = T.dst = 0; T.nPoints = 3 * n; T.dims = P.D; T.S = sys_size(P.D);
+        const int tiles = (T.nPoints + NE_BLOCK - 1) / NE_BLOCK;
+        T.nBlocks = t->maxBatch < 64 ? tiles : (tiles < 4 ? tiles : 4);
+        T.slabOff = slabOff; slabOff += T.nBlocks * T.S;
+        T.cloud = nullptr; T.pot = nullptr;
+        t->ldsTerm[P.nTerms] = sizeof(float) * ((size_t)t->ldsModels + (size_t)NE_BLOCK * noobs_row_len(TERM_POINTS, P.D) + 8);
+        DARTK_REQUIRE(t->ldsTerm[P.nTerms] <= 160 * 1024, "LDS requirement exceeds 160 KiB");
+        if (T.S > t->SMax) t->SMax = T.S;
+        ++P.nTerms;
+    }
+    P.nPointPriors = n;
+    P.pointPriors = t->d_pointPriors;
+    const int newStride = slabOff > 0 ? slabOff : 1;
+    if (newStride != P.slabStride) {
+        if (t->slabs) DARTK_HIP(hipFree(t->slabs));
+        t->slabs = nullptr;
+        P.slabStride = newStride;
+        DARTK_HIP(hipMalloc((void **)&t->slabs, sizeof(float) * (size_t)P.slabStride * t->maxBatch));
+    }
+    const int ldU = (P.D + 1) | 1;
+    const int sysFloats = t->SMax > 12 * t->maxFrames ? t->SMax : 12 * t->maxFrames;
+    t->ldsSolve = sizeof(float) * ((size_t)P.D * ldU + P.D + sysFloats + 8);
+    DARTK_REQUIRE(t->ldsSolve <= 160 * 1024, "LDS requirement exceeds 160 KiB");
+    DARTK_HIP(hipMemcpy(t->d, &P, sizeof(NoObsProblem), hipMemcpyHostToDevice));
+    return DARTK_OK;
+}
+
+extern "C" {
+
+int dartk_noobs_set_point_priors(dartk_noobs_t h, const dartk_point_prior *h_priors, int n, void *stream) {
+    NoObs *t = reinterpret_cast<NoObs *>(h);
+    DARTK_REQUIRE(t && (h_priors || n == 0) && n >= 0, "dartk_noobs_set_point_priors: bad argument");
+    for (int p = 0; p < n; ++p) {
+        const dartk_point_prior &q = h_priors[p];
+        DARTK_REQUIRE(q.srcModel >= 0 && q.srcModel < t->h.nModels, "point prior %d: model %d out of range", p, q.srcModel);
+        DARTK_REQUIRE(q.srcFrame >= 0 && q.srcFrame < t->h.model[q.srcModel].nFrames, "point prior %d: frame %d out of range", p, q.srcFrame);
+        DARTK_REQUIRE(q.kind == 0 || q.kind == 1, "point prior %d: kind must be 0 (3D-3D) or 1 (2D-3D)", p);
+    }
+    DARTK_HIP(hipStreamSynchronize(as_stream(stream)));       // set-up call: the buffers it replaces may still be in use
+    if (n != t->h.nPointPriors) {
+        DARTK_HIP(hipDeviceSynchronize());
+        if (t->d_pointPriors) DARTK_HIP(hipFree(t->d_pointPriors));
+        t->d_pointPriors = nullptr;
+        if (n > 0) DARTK_HIP(hipMalloc((void **)&t->d_pointPriors, sizeof(dartk_point_prior) * (size_t)n));
+        const int rc = noobs_set_points_term(t, n);
+        if (rc) return rc;
+    }
+    if (n > 0) DARTK_HIP(hipMemcpy(t->d_pointPriors, h_priors, sizeof(dartk_point_prior) * (size_t)n, hipMemcpyHostToDevice));
     return DARTK_OK;
 }
 

@@ -54,6 +54,65 @@ class ContactPrior:
         return c
 
 
+@dataclass
+class Point3D3DPrior:
+    """Point3D3DPrior constructor arguments (priors.h:94-101): a point of a source frame is pulled to a camera-frame point."""
+    srcModelID: int
+    srcFrame: int
+    point_c: tuple
+    point_f: tuple
+    weight: float
+
+    kind = 0
+
+    def setWeight(self, w):
+        self.weight = float(w)
+
+    def setTargetCameraPoint(self, p):
+        self.point_c = tuple(float(v) for v in p)
+
+    def getTargetCameraPoint(self):
+        return self.point_c
+
+    def getSourceFramePoint(self):
+        return self.point_f
+
+    def getSourceModelID(self):
+        return self.srcModelID
+
+    def getSourceFrame(self):
+        return self.srcFrame
+
+    def fill(self, c):
+        c.kind, c.srcModel, c.srcFrame, c.weight = self.kind, int(self.srcModelID), int(self.srcFrame), float(self.weight)
+        for k in range(3):
+            c.point_f[k] = float(self.point_f[k])
+            c.point_c[k] = float(self.point_c[k]) if k < len(self.point_c) else 0.0
+        return c
+
+    def sig(self):
+        return (self.kind, self.srcModelID, self.srcFrame, self.weight, tuple(self.point_c), tuple(self.point_f))
+
+
+@dataclass
+class Point2D3DPrior(Point3D3DPrior):
+    """Point2D3DPrior (priors.h:131-141): the point's projection is pulled to a pixel. point_c = (u, v)."""
+    principalPoint: tuple = (0.0, 0.0)
+    focalLength: tuple = (1.0, 1.0)
+
+    kind = 1
+
+    def fill(self, c):
+        Point3D3DPrior.fill(self, c)
+        for k in range(2):
+            c.focalLength[k] = float(self.focalLength[k])
+            c.principalPoint[k] = float(self.principalPoint[k])
+        return c
+
+    def sig(self):
+        return Point3D3DPrior.sig(self) + (tuple(self.principalPoint), tuple(self.focalLength))
+
+
 def priors_array(priors, cls=None):
     cls = cls or _abi.ContactPriorC
     arr = (cls * max(len(priors), 1))()
@@ -73,6 +132,7 @@ class TrackerNoObs:
         self.T_mc = []          # per model, camera->model (Pose::getTransformCameraToModel)
         self.joints = []
         self.priors: List[ContactPrior] = []
+        self.point_priors: List[Point3D3DPrior] = []      # evaluated after the contact priors (device and oracle alike)
         self.opts = OptimizationOptions()
         self.opts.lambdaIntersection = []
         self.opts.regularization = []
@@ -121,6 +181,10 @@ class TrackerNoObs:
         self._handle = None
 
     def addPrior(self, prior):
+        if isinstance(prior, Point3D3DPrior):
+            self.point_priors.append(prior)
+            self._points_sig = None
+            return
         self.priors.append(prior)
         self._handle = None
 
@@ -158,11 +222,17 @@ class TrackerNoObs:
         self._handle = h
         self._terms_key = key
         self._priors_sig = self._sig()
+        self._points_sig = None
 
     def _sig(self):
         return [(p.weight, tuple(p.contactPoint), p.contactThreshold) for p in self.priors]
 
     def _sync_priors(self):
+        psig = [p.sig() for p in self.point_priors]
+        if getattr(self, "_points_sig", None) != psig and (psig or getattr(self, "_points_sig", None)):
+            arr = priors_array(self.point_priors, _abi.PointPriorC)
+            check(lib().dartk_noobs_set_point_priors(self._handle, arr, len(self.point_priors), device._stream()))
+        self._points_sig = psig
         if self._priors_sig != self._sig():
             arr = priors_array(self.priors)
             check(lib().dartk_noobs_set_priors(self._handle, arr, len(self.priors), device._stream()))

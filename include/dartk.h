@@ -252,6 +252,23 @@ int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *co
 int dartk_noobs_destroy(dartk_noobs_t t);
 /* ContactPrior::setWeight / setContactThreshold / contact point resets (priors.h:66-67, grasp_analyzer.cpp:941-981) */
 int dartk_noobs_set_priors(dartk_noobs_t t, const dartk_contact_prior *h_priors, int nPriors, void *stream);
+/* Point3D3DPrior / Point2D3DPrior (src/optimization/priors.h:92-170; computeContribution point_3d_3d_prior.cpp:6-69,
+ * point_2d_3d_prior.cpp:6-83): a point fixed in a frame of the source model is pulled to a camera-frame point (kind 0:
+ * residual = R_mc (p_c - target), 3 rows) or to a pixel (kind 1: residual = projection - target, 2 rows). They add
+ * w J^T J and w J^T e to the source model's block and nothing to the energy (their _error stays 0), but count in the
+ * energy's division by priors.size() (optimizer.cpp:1068). */
+typedef struct dartk_point_prior {
+    int32_t kind;               /* 0 Point3D3DPrior, 1 Point2D3DPrior */
+    int32_t srcModel, srcFrame;
+    float weight;
+    float point_f[3];           /* _point_f: the point in the source frame */
+    float point_c[3];           /* _point_c: target, camera frame (kind 0) or pixel x, y (kind 1; [2] unused) */
+    float focalLength[2], principalPoint[2];    /* kind 1 */
+} dartk_point_prior;
+/* Replaces the tracker's list of point priors (TrackerNoObs::addPrior, tracker_no_obs.h:47); evaluated after the contact
+ * priors. A set-up call: synchronises, and re-allocates the partial-system buffer when n changes. */
+int dartk_noobs_set_point_priors(dartk_noobs_t t, const dartk_point_prior *h_priors, int nPriors, void *stream);
+
 /* OptimizerNoObs::optimizePoses (optimizer.h:141-160 / optimizer.cpp:783-983) for `batch` independent candidates
  * (NullReduction poses): per iteration self- and pairwise intersection terms, every contact prior
  * (ContactPrior::computeContribution, contact_prior.cpp:8-205), regularisation + LM damping after the priors, the

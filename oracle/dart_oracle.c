@@ -1100,3 +1100,60 @@ static float contact_prior_contribution_(const orc_contact_prior *p, const orc_m
     free(subJ);
     return error;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Point3D3DPrior / Point2D3DPrior::computeContribution (point_3d_3d_prior.cpp:6-69, point_2d_3d_prior.cpp:6-83)
+ * ---------------------------------------------------------------------------------------------- */
+void orc_point_prior_contribution(const orc_point_prior *p, const orc_model *const *models, const float *const *T_mcs,
+                                  const float *const *T_cms, const float *const *T_fms, const float *const *T_mfs,
+                                  const int32_t *modelOffsets, const int32_t *modelDims, float *JTJ, int sys, float *JTe) {
+    if (p->weight == 0) return;
+    const orc_model *src = models[p->srcModel];
+    const int srcOffset = modelOffsets[p->srcModel], srcDims = modelDims[p->srcModel];
+    const float *T_mf = T_mfs[p->srcModel] + 12 * p->srcFrame;
+    float T_fc[12];
+    orc_se3_mul(T_cms[p->srcModel], T_mf, T_fc);              /* getTransformFrameToCamera = T_cm * T_mf */
+    const float pf[4] = {p->point_f[0], p->point_f[1], p->point_f[2], 1};
+    float pc[4], pm[4];
+    se3_apply4(T_fc, pf, pc);
+    se3_apply4(T_mf, pf, pm);
+    const int rows = p->kind == 0 ? 3 : 2;
+    float subE[3] = {0, 0, 0};
+    float g[3][3];       /* row k of subJ is dot(g[k], J3D_i) with g in the model frame */
+    if (p->kind == 0) {
+        const float dc[3] = {pc[0] - p->point_c[0], pc[1] - p->point_c[1], pc[2] - p->point_c[2]};
+        const float dist = sqrtf(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]);
+        if (dist == 0) return;
+        se3_rotate3(T_mcs[p->srcModel], dc, subE);              /* diff_m */
+        for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) g[k][a] = (k == a) ? 1.0f : 0.0f;
+    } else {
+        const float fx = p->focalLength[0], fy = p->focalLength[1];
+        const float px = pc[0] * fx / pc[2] + p->principalPoint[0];
+        const float py = pc[1] * fy / pc[2] + p->principalPoint[1];
+        const float dx = px - p->point_c[0], dy = py - p->point_c[1];
+        if (sqrtf(dx * dx + dy * dy) == 0) return;
+        subE[0] = dx; subE[1] = dy;
+        /* subJ(k,i) = dot(gc_k, R_cm J3D_i) = dot(R_mc gc_k, J3D_i) */
+        const float gc0[3] = {fx / pc[2], 0, -(pc[0]) * fx / (pc[2] * pc[2])};
+        const float gc1[3] = {0, fy / pc[2], -(pc[1]) * fy / (pc[2] * pc[2])};
+        se3_rotate3(T_mcs[p->srcModel], gc0, g[0]);
+        se3_rotate3(T_mcs[p->srcModel], gc1, g[1]);
+    }
+    float *J3 = (float *)malloc(sizeof(float) * 3 * (size_t)(6 + src->n_joints));
+    float *subJ = (float *)malloc(sizeof(float) * 3 * (size_t)srcDims);
+    orc_model_jacobian_3d(src, T_fms[p->srcModel], T_mfs[p->srcModel], pm, p->srcFrame, J3);
+    for (int k = 0; k < rows; ++k)
+        for (int i = 0; i < srcDims; ++i) subJ[k * srcDims + i] = dot3(g[k], J3 + 3 * i);
+    for (int i = 0; i < srcDims; ++i) {
+        float v = 0;
+        for (int k = 0; k < rows; ++k) v += (p->weight * subJ[k * srcDims + i]) * subE[k];
+        JTe[srcOffset + i] += v;
+    }
+    for (int i = 0; i < srcDims; ++i) for (int j = i; j < srcDims; ++j) {
+        float v = 0;
+        for (int k = 0; k < rows; ++k) v += (p->weight * subJ[k * srcDims + i]) * subJ[k * srcDims + j];
+        if (v == 0) continue;
+        JTJ[(srcOffset + i) * sys + srcOffset + j] += v;
+    }
+    free(J3); free(subJ);
+}

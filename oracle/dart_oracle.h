@@ -182,6 +182,21 @@ float orc_contact_prior_contribution(const orc_contact_prior *p, const orc_model
                                      int priorParamOffset, float *JTJ, int sys, float *JTe,
                                      int32_t *dstSdfOut);
 
+/* ---- keypoint priors (point_3d_3d_prior.cpp:6-69, point_2d_3d_prior.cpp:6-83) ---- */
+typedef struct {
+    int32_t kind;               /* 0 Point3D3DPrior, 1 Point2D3DPrior */
+    int32_t srcModel, srcFrame;
+    float weight;
+    float point_f[3];           /* _point_f */
+    float point_c[3];           /* _point_c (kind 1: pixel x, y) */
+    float focalLength[2], principalPoint[2];
+} orc_point_prior;
+/* Evaluates one prior: adds _weight * subJ^T subJ (upper triangle, zeros skipped) and _weight * subJ^T subE into the
+ * source model's block. These priors never set _error (it stays 0). */
+void orc_point_prior_contribution(const orc_point_prior *p, const orc_model *const *models, const float *const *T_mcs,
+                                  const float *const *T_cms, const float *const *T_fms, const float *const *T_mfs,
+                                  const int32_t *modelOffsets, const int32_t *modelDims, float *JTJ, int sys, float *JTe);
+
 #ifdef __cplusplus
 }
 #endif

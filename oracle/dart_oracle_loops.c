@@ -178,6 +178,10 @@ static float noobs_intersection_terms(noobs_ctx *c, const orc_model *const *mode
     return total;
 }
 
+static const orc_point_prior *g_pointPriors = NULL;
+static int g_nPointPriors = 0;
+void orc_noobs_set_point_priors(const orc_point_prior *priors, int n) { g_pointPriors = n > 0 ? priors : NULL; g_nPointPriors = n > 0 ? n : 0; }
+
 float orc_get_error_noobs(const orc_model *const *models, float *const *T_mcs, float *const *joints,
                           const orc_noobs_options *o, const float *const *clouds, const int32_t *nClouds,
                           const int32_t *const *potentials, const orc_contact_prior *priors, int nPriors) {
@@ -200,7 +204,7 @@ float orc_get_error_noobs(const orc_model *const *models, float *const *T_mcs, f
     for (int p = 0; p < nPriors; ++p)
         pe += orc_contact_prior_contribution(&priors[p], models, c.cT_mc, c.cT_cm, c.cT_fm, c.cT_mf, c.offs, c.dims, c.priorOff[p],
                                              JTJ, c.sys, JTe, NULL);
-    if (nPriors > 0) error += pe / (float)nPriors;
+    if (nPriors + g_nPointPriors > 0) error += pe / (float)(nPriors + g_nPointPriors);   /* point priors: _error == 0 */
     free(JTJ); free(JTe);
     noobs_free(&c);
     return error;
@@ -241,6 +245,8 @@ float orc_optimize_poses_noobs(const orc_model *const *models, float *const *T_m
             ePri += e;
             (void)ds;
         }
+        for (int p = 0; p < g_nPointPriors; ++p)
+            orc_point_prior_contribution(&g_pointPriors[p], models, c.cT_mc, c.cT_cm, c.cT_fm, c.cT_mf, c.offs, c.dims, JTJ, sysN, JTe);
         if (it == 0 && firstSystem) {
             for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) firstSystem[i * D + j] = JTJ[i * sysN + j];
             for (int i = 0; i < D; ++i) firstSystem[D * D + i] = JTe[i];

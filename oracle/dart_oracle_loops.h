@@ -78,6 +78,10 @@ float orc_optimize_poses_noobs(const orc_model *const *models, float *const *T_m
                                const orc_noobs_options *o, const float *const *clouds, const int32_t *nClouds,
                                const int32_t *const *potentials, const orc_contact_prior *priors, int nPriors,
                                float *iterInfo, float *firstSystem);
+/* Keypoint priors for the two NoObs functions below: evaluated after the contact priors (the reference walks one mixed
+ * list in insertion order; the order only fixes the order of the sums) and counted in getError's division by
+ * priors.size(). The pointer is kept, not copied; n = 0 clears it. */
+void orc_noobs_set_point_priors(const orc_point_prior *priors, int n);
 /* OptimizerNoObs::getError (optimizer.cpp:985-1076) */
 float orc_get_error_noobs(const orc_model *const *models, float *const *T_mcs, float *const *joints,
                           const orc_noobs_options *o, const float *const *clouds, const int32_t *nClouds,

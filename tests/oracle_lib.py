@@ -31,6 +31,24 @@ class OrcContactPrior(C.Structure):
                 ("updateContact", C.c_int32)]
 
 
+class OrcPointPrior(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("srcModel", C.c_int32), ("srcFrame", C.c_int32), ("weight", C.c_float),
+                ("point_f", C.c_float * 3), ("point_c", C.c_float * 3), ("focalLength", C.c_float * 2),
+                ("principalPoint", C.c_float * 2)]
+
+
+_point_keep = []
+
+
+def set_point_priors(point_priors):
+    """orc_noobs_set_point_priors: keypoint priors for the following NoObs calls ([] clears)."""
+    arr = (OrcPointPrior * max(len(point_priors), 1))()
+    for k, p in enumerate(point_priors):
+        p.fill(arr[k])
+    _point_keep[:] = [arr]
+    lib().orc_noobs_set_point_priors(arr, len(point_priors))
+
+
 def build():
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h")) or f == "Makefile"]
     if not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):

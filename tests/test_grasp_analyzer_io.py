@@ -82,3 +82,35 @@ def test_compare_poses():
     b = a.copy()
     b[0, 3], b[1, 11] = 1.0, 2.0
     assert GA.compare_poses(a, b) == 5.0
+
+
+def test_keypoints_and_dof_sample_files(tmp_path):
+    """HandFitter's inputs (hand_fitter.cpp:121-171). The reference's keypoints.txt is read where the tree is present."""
+    from dart_amd import hand_fitter as HF
+    p = tmp_path / "keypoints.txt"
+    p.write_text("palm palm 44.7881 0 -1.27377\nindex2 index1 -22.9145 15.5859 -1.53697\n")
+    kp = HF.read_keypoints(str(p), offsets={"index1": (1.0, 0.0, 0.0)})
+    assert kp["palm"][0] == 0 and abs(kp["palm"][1][0][0] - 0.0447881) < 1e-9 and kp["palm"][1][1] == (0.0, 0.0, 0.0)
+    assert kp["index2"][0] == 2 and abs(kp["index2"][1][0][0] + 0.0219145) < 1e-9
+    d = tmp_path / "dof_samples.txt"
+    d.write_text("0.1,0.2,0.3\n0.4,0.5,0.6,\n")
+    np.testing.assert_allclose(HF.read_dof_samples(str(d), 3), [[0.1, 0.2, 0.3], [0.4, 0.5, 0.6]], rtol=1e-6)
+    ref = "/root/reference/models/HumanHand/keypoints.txt"
+    if os.path.exists(ref):
+        kp = HF.read_keypoints(ref)
+        assert len(kp) == 21 and kp["thumb4"][0] == 20
+
+
+def test_umeyama_recovers_similarity():
+    from dart_amd import hand_fitter as HF
+    rng = np.random.default_rng(1)
+    src = rng.normal(size=(3, 7))
+    A = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    A *= np.sign(np.linalg.det(A))
+    dst = 1.3 * A @ src + np.array([[0.2], [-0.1], [0.5]])
+    T = HF.umeyama(src, dst, True)
+    np.testing.assert_allclose(T[:3, :3], 1.3 * A, atol=1e-9)
+    np.testing.assert_allclose(T[:3, 3], [0.2, -0.1, 0.5], atol=1e-9)
+    dst[:, 0] += 0.5                        # one outlier: RANSAC keeps the other six
+    T2 = HF.estimate_srt(src, dst, n_iters=60, rng=np.random.default_rng(0))
+    np.testing.assert_allclose(T2[:3, :3], 1.3 * A, atol=1e-6)
