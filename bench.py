@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--grasp-steps", type=int, default=3)
     ap.add_argument("--no-grasps", action="store_true")
     ap.add_argument("--no-tracking", action="store_true", help="profiling aid: skip the headline leg's timed loop")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="test aid for a 1-GPU box: every rank uses cuda:0 and the ranks talk over gloo (RCCL refuses two ranks on one device); "
+                         "exercises the sharding / gather / max-over-ranks code of the multi-GPU launch, the numbers mean nothing")
     args = ap.parse_args()
 
     import torch
@@ -107,10 +110,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     D.init(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -124,7 +132,7 @@ def main():
     def max_over_ranks(x):
         if not distributed:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -162,6 +170,8 @@ def main():
     info = opt.iter_info.cpu().numpy()
     rec = torch.tensor(np.concatenate([[info[-1, 0] + info[-1, 1]], T_mc, joints]).astype(np.float32), device=dev)
     if distributed:
+        if args.rehearse_on_one_gpu:
+            rec = rec.cpu()
         out = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(out, rec)
 

@@ -26,8 +26,14 @@ def gather_candidates(n, rank, world, energy, poses):
     k = energy.shape[0]
     rec[:k, 0] = energy
     rec[:k, 1:] = poses
-    out = [torch.empty_like(rec) for _ in range(world)]
-    dist.all_gather(out, rec)
+    if dist.get_backend() == "gloo" and rec.is_cuda:       # gloo has no all_gather for device tensors (CPU tests, rehearsals)
+        host = rec.cpu()
+        out = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(out, host)
+        out = [o.to(rec.device) for o in out]
+    else:
+        out = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(out, rec)
     full_e = torch.empty(n, dtype=torch.float32, device=energy.device)
     full_p = torch.empty((n, P), dtype=torch.float32, device=energy.device)
     for r in range(world):
