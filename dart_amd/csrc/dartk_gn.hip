@@ -706,6 +706,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     // association the same way, optimizer.cpp:610-639). Each chain alone leaves most of the chip idle.
     const bool fork = useA && useB && o->numIterations > 0;
     hipStream_t stB = fork ? ws->auxStream : st;
+    DARTK_HIP(hipMemsetAsync(ws->counters, 0, 2 * sizeof(int), st));      // before the fork; later iterations: zeroed by the solve kernel
     if (fork) {
         DARTK_HIP(hipEventRecord(ws->evFork, st));
         DARTK_HIP(hipStreamWaitEvent(stB, ws->evFork, 0));
@@ -724,7 +725,6 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     if (ldsS > 64 * 1024)
         DARTK_HIP(hipFuncSetAttribute((const void *)gn_solve_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS));
 
-    DARTK_HIP(hipMemsetAsync(ws->counters, 0, 2 * sizeof(int), st));      // later iterations: zeroed by the solve kernel
     if (useA && o->numIterations > 0) {
         ProfScope ps(DARTK_PROF_OTHER, st);
         hipLaunchKernelGGL(valid_count_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, st, (const float4 *)d_vert, nPix, vcOffsets);

@@ -20,6 +20,11 @@ struct SdfDev {               // 64 bytes
     int dimx, dimy, dimz;
     int dataOff;              // offset (in floats) of this grid in the model's grid arena
     float ox, oy, oz, res;
+    // x / res without the IEEE division sequence (~12 instructions): q0 = x*rcpRes, q = fma(fma(-q0, res, x), rcpRes, q0).
+    // divExact is set at model creation only if that equals the correctly rounded x / res for EVERY fp32 significand x
+    // (exhaustive check of the 2^23 significands for this res; the result is exponent independent), else the kernels divide.
+    float rcpRes;
+    int divExact;
     // exact float images of the reference's double-literal bound tests (grid_3d.h:63-80):
     //   p > 2.50001  <=>  p >= lo25 ;   p < dim - 2.50001  <=>  p <= hi25{x,y,z}
     float lo25, hi25x, hi25y, hi25z;
@@ -169,11 +174,17 @@ __device__ __forceinline__ void se3_invert(const float *A, float *o) {
 // expressions (p - 0.5), (int)(p - 0.5) and the fraction are exactly representable in fp32, so evaluating
 // them in fp32 gives bit-identical x0 / fx (DESIGN.md "mixed precision"); the double-literal bound tests
 // are replaced by their exact float images precomputed on the host.
+// x / res, correctly rounded, for a res whose reciprocal sequence was verified (SdfDev::divExact)
+__device__ __forceinline__ float div_exact(float x, float res, float rcp) {
+    const float q0 = x * rcp;
+    return __builtin_fmaf(__builtin_fmaf(-q0, res, x), rcp, q0);
+}
 __device__ __forceinline__ f3 grid_coords(const SdfDev &s, f3 p) {        // grid_3d.h:49-51
+    const float res = s.res, rcp = s.rcpRes;
+    const float dx = p.x - s.ox, dy = p.y - s.oy, dz = p.z - s.oz;
     f3 g;
-    g.x = (p.x - s.ox) / s.res;
-    g.y = (p.y - s.oy) / s.res;
-    g.z = (p.z - s.oz) / s.res;
+    if (s.divExact) { g.x = div_exact(dx, res, rcp); g.y = div_exact(dy, res, rcp); g.z = div_exact(dz, res, rcp); }
+    else { g.x = dx / res; g.y = dy / res; g.z = dz / res; }
     return g;
 }
 __device__ __forceinline__ bool in_bounds_grad_interp(const SdfDev &s, f3 g) {  // grid_3d.h:76-80

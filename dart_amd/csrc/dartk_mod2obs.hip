@@ -108,20 +108,27 @@ raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int 
     }
     if (march) {
         const float *data = m.grids + sdf.dataOff;
+        // header fields in registers for the march (the compiler does not hoist loads through the SdfDev reference)
+        const float res = sdf.res, rcp = sdf.rcpRes, ox = sdf.ox, oy = sdf.oy, oz = sdf.oz;
+        const bool exactDiv = sdf.divExact != 0;
+        const int dimx = sdf.dimx, dimy = sdf.dimy;
         auto eval = [&](float tt) -> float {
             f3 xf, xg;
             xf.x = dn.x * tt + of.x; xf.y = dn.y * tt + of.y; xf.z = dn.z * tt + of.z;
-            xg.x = fmaxf(1.0f, fminf((xf.x - sdf.ox) / sdf.res, hix));
-            xg.y = fmaxf(1.0f, fminf((xf.y - sdf.oy) / sdf.res, hiy));
-            xg.z = fmaxf(1.0f, fminf((xf.z - sdf.oz) / sdf.res, hiz));
-            return grid_value(data, sdf.dimx, sdf.dimy, xg) * sdf.res;
+            const float dx = xf.x - ox, dy = xf.y - oy, dz = xf.z - oz;
+            if (exactDiv) { xg.x = div_exact(dx, res, rcp); xg.y = div_exact(dy, res, rcp); xg.z = div_exact(dz, res, rcp); }
+            else { xg.x = dx / res; xg.y = dy / res; xg.z = dz / res; }
+            xg.x = fmaxf(1.0f, fminf(xg.x, hix));
+            xg.y = fmaxf(1.0f, fminf(xg.y, hiy));
+            xg.z = fmaxf(1.0f, fminf(xg.z, hiz));
+            return grid_value(data, dimx, dimy, xg) * res;
         };
         float sdfValPrev = eval(t0);
         float tPrev = t0;
 #ifdef DARTK_STAMPS
         int steps = 0;
 #endif
-        const float minStep = sdf.res / 10;
+        const float minStep = res / 10;
         while (t0 < t1 && t0 < 10000.0f) {      // 10000 = the reference's initial closestT
             const float sdfVal = eval(t0);
             if (sdfValPrev > levelSet && sdfVal <= levelSet) {
@@ -399,7 +406,10 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
     int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ld);
     float *sRT = reinterpret_cast<float *>(waveCnt + 8);       // REPLAY: per-SDF ray transforms, 24 * nSdfs floats
     stage_model(m, sT_fm, sT_mf, nullptr);
-    if (REPLAY) replay_stage_transforms(m, 0, m.nSdfs, sRT);    // nSdfs <= NE_BLOCK checked by the launcher
+    if (REPLAY) {       // nSdfs <= NE_BLOCK checked by the launcher; every thread reads sRT in the first tile already
+        replay_stage_transforms(m, 0, m.nSdfs, sRT);
+        __syncthreads();
+    }
     float T_gc[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T_gc[i] = T_gc_in[i];

@@ -8,8 +8,11 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <cmath>
 #include <vector>
+#include <utility>
 
 namespace dartk {
 
@@ -173,7 +176,32 @@ static float next_below(double v) {   // largest float strictly less than v
     while ((double)nextafterf(f, INFINITY) < v) f = nextafterf(f, INFINITY);
     return f;
 }
+// true iff q = fma(fma(-(x*r), c, x), r, x*r) with r = RN(1/c) equals RN(x / c) for every fp32 significand x in [1, 2)
+// (both sides scale exactly with the exponent of x as long as nothing is subnormal). ~20 ms per distinct c, memoised.
+static bool division_by_constant_is_exact(float c) {
+    static std::vector<std::pair<float, bool>> memo;
+    for (const auto &e : memo) if (e.first == c) return e.second;
+    bool ok = c > 0 && std::isfinite(c) && std::isnormal(1.0f / c);
+    if (ok) {
+        const float r = 1.0f / c;
+        for (uint32_t m = 0; m < (1u << 23) && ok; ++m) {
+            uint32_t bits = 0x3f800000u | m;
+            float x;
+            memcpy(&x, &bits, 4);
+            const float q0 = x * r;
+            const float q = std::fmaf(std::fmaf(-q0, c, x), r, q0);
+            ok = (q == x / c);
+        }
+    }
+    memo.emplace_back(c, ok);
+    return ok;
+}
+
 static void fill_bounds(SdfDev &s) {
+    s.rcpRes = s.res > 0 ? 1.0f / s.res : 0.0f;
+    // DARTK_NO_FASTDIV=1 (diagnostic): always divide
+    static const bool noFast = getenv("DARTK_NO_FASTDIV") != nullptr;
+    s.divExact = (!noFast && s.res > 0 && division_by_constant_is_exact(s.res)) ? 1 : 0;
     s.lo25 = next_above(2.50001);
     s.hi25x = next_below((double)(unsigned)s.dimx - 2.50001);
     s.hi25y = next_below((double)(unsigned)s.dimy - 2.50001);
