@@ -68,19 +68,20 @@ def tr_slab_floats(tr):
     def S(d):
         return d + d * (d + 1) // 2 + 1
     total = 0
-    many = tr.max_batch >= 64
+    mb = tr.max_batch       # noobs_blocks_per_term (dartk_noobs.hip)
+    want = 1 << 30 if mb < 64 else 16 if mb < 128 else 8 if mb < 512 else 4 if mb < 2048 else 2
     n = len(tr.models)
     lam = tr.opts.lambdaIntersection
     for m in range(n):
         tiles = (tr.clouds[m].shape[0] + 127) // 128
-        blocks = min(tiles, 4) if many else tiles
+        blocks = min(tiles, want)
         if lam[m + m * n] > 0 and tr.models[m].dims > 6:
             total += blocks * S(tr.models[m].dims - 6)
         for d in range(n):
             if d != m and lam[m + d * n] > 0:
                 total += blocks * S(tr.models[m].dims)
     tiles = (len(tr.priors) + 127) // 128
-    return total, (min(tiles, 4) if many else tiles) * S(D_)
+    return total, min(tiles, want) * S(D_)
 
 
 def main():

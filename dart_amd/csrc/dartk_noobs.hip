@@ -16,11 +16,15 @@
 #include "dartk_kernels.h"
 #include "dartk_fk.h"
 
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
 namespace dartk {
 
+#ifndef NOOBS_ROWS
+#define NOOBS_ROWS 32        // rows of parked active points per workgroup (<= NE_BLOCK)
+#endif
 enum { TERM_SELF = 0, TERM_INTER = 1, TERM_PRIORS = 2, TERM_POINTS = 3 };
 __host__ __device__ constexpr bool term_weighted(int type) { return type == TERM_PRIORS || type == TERM_POINTS; }
 static constexpr int NOOBS_MAX_TERMS = DARTK_MAX_MODELS * DARTK_MAX_MODELS + 2;
@@ -58,6 +62,19 @@ __device__ unsigned long long g_noobsStamps[3][8];
 #else
 #define NOOBS_STAMP(ph) do { } while (0)
 #endif
+
+// workgroups (= partial systems) of one term of one candidate. Every workgroup pays a fixed prologue (pose tables, spheres,
+// accumulator set-up, slab store), so large batches use few workgroups per term and small ones one per tile.
+static int noobs_blocks_per_term(int tiles, int maxBatch) {
+    if (tiles < 1) return 1;
+    int want = tiles;
+    if (maxBatch >= 64) {
+        static const char *env = getenv("DARTK_NOOBS_BLOCKS");      // diagnostic override
+        // measured optimum on MI355X (tools/sweep_noobs_blocks.sh, C4 scene): 8 at 256 candidates, 4 at 1024, 2 at 4096
+        want = env ? atoi(env) : (maxBatch < 128 ? 16 : maxBatch < 512 ? 8 : maxBatch < 2048 ? 4 : 2);
+    }
+    return want < tiles ? (want > 0 ? want : 1) : tiles;
+}
 
 // LDS row length of a term: the packed-system row, and at least the parked state of an active point (8 / 16 floats)
 __host__ __device__ inline int noobs_row_len(int type, int d) {
@@ -145,7 +162,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     const int d = T.dims;
     const int ld = noobs_row_len(TYPE, d);
     float *rows = lds + sSphOff[nModels];
-    int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ld);
+    int *waveCnt = reinterpret_cast<int *>(rows + NOOBS_ROWS * ld);
     int *sPot = waveCnt + 8;            // the self term's potential-intersection matrix (when it fits)
     const ModelView src = rebase(P->model[T.src], poseC + P->poseOff[T.src]);
     const ModelView dst = rebase(P->model[T.dst], poseC + P->poseOff[T.dst]);
@@ -381,18 +398,24 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         NOOBS_STAMP(2);
         int nActive;
         const int slot = compact_slot<NE_BLOCK>(active, waveCnt, nActive);
-        if (pending + nActive > NE_BLOCK) { flush(pending); pending = 0; }
-        if (active) {
-            float *e = rows + (pending + slot) * ld;
-            e[0] = pm.x; e[1] = pm.y; e[2] = pm.z; e[3] = gs.x; e[4] = gs.y; e[5] = gs.z; e[6] = residual;
-            if constexpr (WEIGHTED) {
-                e[7] = __int_as_float(srcFrame | (dstFrame << 8) | (pSrc << 16) | (pDst << 20) | ((int)upSrc << 24) | ((int)upDst << 25));
-                e[8] = pdm.x; e[9] = pdm.y; e[10] = pdm.z; e[11] = gdm.x; e[12] = gdm.y; e[13] = gdm.z; e[14] = weight; e[15] = E;
-            } else {
-                e[7] = __int_as_float(srcFrame);
+        // the row buffer holds NOOBS_ROWS rows (small, so that LDS does not set the occupancy): park what fits, flush, repeat
+        for (int base = 0;;) {
+            const int room = NOOBS_ROWS - pending;
+            const int take = (nActive - base < room) ? nActive - base : room;
+            if (active && slot >= base && slot < base + take) {
+                float *e = rows + (pending + slot - base) * ld;
+                e[0] = pm.x; e[1] = pm.y; e[2] = pm.z; e[3] = gs.x; e[4] = gs.y; e[5] = gs.z; e[6] = residual;
+                if constexpr (WEIGHTED) {
+                    e[7] = __int_as_float(srcFrame | (dstFrame << 8) | (pSrc << 16) | (pDst << 20) | ((int)upSrc << 24) | ((int)upDst << 25));
+                    e[8] = pdm.x; e[9] = pdm.y; e[10] = pdm.z; e[11] = gdm.x; e[12] = gdm.y; e[13] = gdm.z; e[14] = weight; e[15] = E;
+                } else {
+                    e[7] = __int_as_float(srcFrame);
+                }
             }
+            pending += take; base += take;
+            if (base >= nActive) break;
+            flush(pending); pending = 0;        // full
         }
-        pending += nActive;
         __syncthreads();
         NOOBS_STAMP(3);
     }
@@ -670,7 +693,6 @@ int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *co
         }
     }
     // term table in the reference's evaluation order: per model self-intersection, then the other models; priors last
-    const bool small = maxBatch < 64;     // few candidates: one workgroup per tile; many: a few workgroups per term
     int nTerms = 0, slabOff = 0, SMax = 0;
     int ldsModels = 0, potInts = 0;
     for (int m = 0; m < nModels; ++m) {
@@ -682,12 +704,12 @@ int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *co
         NoObsTerm &T = P.term[nTerms++];
         T.type = type; T.src = src; T.dst = dst; T.nPoints = nPoints; T.dims = dims; T.S = sys_size(dims);
         const int tiles = (nPoints + NE_BLOCK - 1) / NE_BLOCK;
-        T.nBlocks = small ? (tiles > 0 ? tiles : 1) : (tiles < 4 ? (tiles > 0 ? tiles : 1) : 4);
+        T.nBlocks = noobs_blocks_per_term(tiles, maxBatch);
         T.slabOff = slabOff; slabOff += T.nBlocks * T.S;
         T.cloud = reinterpret_cast<const float4 *>(cloud); T.pot = pot;
         if (T.S > SMax) SMax = T.S;
         const int ld = noobs_row_len(type, dims);
-        t->ldsTerm[nTerms - 1] = sizeof(float) * ((size_t)ldsModels + (size_t)NE_BLOCK * ld + 8 + (type == TERM_SELF ? t->potLdsInts : 0));
+        t->ldsTerm[nTerms - 1] = sizeof(float) * ((size_t)ldsModels + (size_t)NOOBS_ROWS * ld + 8 + (type == TERM_SELF ? t->potLdsInts : 0));
     };
     for (int m = 0; m < nModels; ++m) {
         if (h_lambdaIntersection[m + m * nModels] > 0 && nCloudPoints[m] > 0 && P.dims[m] > 6) {
@@ -754,10 +776,10 @@ static int noobs_set_points_term(NoObs *t, int n) {
         NoObsTerm &T = P.term[P.nTerms];
         T.type = TERM_POINTS; T.src = T.dst = 0; T.nPoints = 3 * n; T.dims = P.D; T.S = sys_size(P.D);
         const int tiles = (T.nPoints + NE_BLOCK - 1) / NE_BLOCK;
-        T.nBlocks = t->maxBatch < 64 ? tiles : (tiles < 4 ? tiles : 4);
+        T.nBlocks = noobs_blocks_per_term(tiles, t->maxBatch);
         T.slabOff = slabOff; slabOff += T.nBlocks * T.S;
         T.cloud = nullptr; T.pot = nullptr;
-        t->ldsTerm[P.nTerms] = sizeof(float) * ((size_t)t->ldsModels + (size_t)NE_BLOCK * noobs_row_len(TERM_POINTS, P.D) + 8);
+        t->ldsTerm[P.nTerms] = sizeof(float) * ((size_t)t->ldsModels + (size_t)NOOBS_ROWS * noobs_row_len(TERM_POINTS, P.D) + 8);
         DARTK_REQUIRE(t->ldsTerm[P.nTerms] <= 160 * 1024, "LDS requirement exceeds 160 KiB");
         if (T.S > t->SMax) t->SMax = T.S;
         ++P.nTerms;
