@@ -16,6 +16,7 @@
 #include "dartk_kernels.h"
 #include "dartk_fk.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -120,8 +121,14 @@ noobs_load_poses_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ 
 // register budget of the contact-prior path does not set the occupancy of the intersection paths.
 // LDS: per model [T_fm | T_mf] (24*nFrames) | per model spheres (20*nSdfs) | rows | wave counters | potential-intersection matrix (self term)
 // -----------------------------------------------------------------------------------------------------
+#ifndef NOOBS_WAVES_PRIORS
+#define NOOBS_WAVES_PRIORS 4
+#endif
+#ifndef NOOBS_WAVES_INTER
+#define NOOBS_WAVES_INTER 5
+#endif
 template <int TPT, int TYPE>
-__global__ void __launch_bounds__(NE_BLOCK)
+__global__ void __launch_bounds__(NE_BLOCK) __attribute__((amdgpu_waves_per_eu(term_weighted(TYPE) ? NOOBS_WAVES_PRIORS : NOOBS_WAVES_INTER)))
 noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses, float *__restrict__ slabs, int termIdx, int potLdsInts) {
     extern __shared__ float lds[];
 #ifdef DARTK_STAMPS
@@ -601,6 +608,16 @@ static int noobs_launch_term(NoObs *t, int term, int batch, hipStream_t st) {
     auto kfn = noobs_terms_kernel<TPT, TYPE>;
     const size_t lds = t->ldsTerm[term];
     if (lds > 64 * 1024) DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const bool dbgOcc = getenv("DARTK_DEBUG_OCCUPANCY") != nullptr;      // diagnostic: resident workgroups per CU
+    if (dbgOcc) {
+        static bool once[4][3];
+        if (!once[TYPE][TPT]) {
+            once[TYPE][TPT] = true;
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, NE_BLOCK, lds);
+            fprintf(stderr, "[dartk] noobs_terms_kernel<%d,%d>: %zu B dynamic LDS, %d workgroups of %d threads per CU\n", TPT, TYPE, lds, nb, NE_BLOCK);
+        }
+    }
     hipLaunchKernelGGL(kfn, dim3(t->h.term[term].nBlocks, batch), dim3(NE_BLOCK), lds, st, t->d, t->poses, t->slabs, term, t->potLdsInts);
     return DARTK_OK;
 }
