@@ -54,6 +54,22 @@ class PointPriorC(C.Structure):
                 ("principalPoint", C.c_float * 2)]
 
 
+class MultiModelC(C.Structure):
+    """dartk_multi_model (include/dartk.h)"""
+    _fields_ = [("model", C.c_void_p), ("redType", C.c_int32), ("redArtDims", C.c_int32), ("d_A", C.c_void_p), ("d_map", C.c_void_p),
+                ("h_b", C.POINTER(C.c_float)), ("h_redMin", C.POINTER(C.c_float)), ("h_redMax", C.POINTER(C.c_float)),
+                ("d_redArt", C.c_void_p), ("d_cloud", C.c_void_p), ("nCloud", C.c_int32), ("d_potential", C.c_void_p),
+                ("d_pts", C.c_void_p), ("distThreshold", C.c_float), ("planeOffset", C.c_float), ("planeNormal", C.c_float * 3),
+                ("regularization", C.c_float), ("regularizationScaled", C.c_float)]
+
+
+class MultiOptionsC(C.Structure):
+    """dartk_multi_options (include/dartk.h)"""
+    _fields_ = [("numIterations", C.c_int32), ("nModels", C.c_int32), ("lambdaObsToMod", C.c_float), ("lambdaModToObs", C.c_float),
+                ("huberDelta", C.c_float), ("focalLength", C.c_float), ("predWidth", C.c_int32), ("predHeight", C.c_int32),
+                ("predFl", C.c_float * 2), ("lambdaIntersection", C.c_float * 64)]
+
+
 class NoObsOptions(C.Structure):
     """dartk_noobs_options (include/dartk.h); orc_noobs_options has the same layout."""
     _fields_ = [("numIterations", C.c_int32), ("nModels", C.c_int32), ("regularization", C.c_float * 8),
@@ -159,6 +175,7 @@ def lib():
         "dartk_noobs_destroy": [vp],
         "dartk_noobs_set_priors": [vp, C.POINTER(ContactPriorC), C.c_int, vp],
         "dartk_noobs_set_point_priors": [vp, C.POINTER(PointPriorC), C.c_int, vp],
+        "dartk_optimize_poses": [C.POINTER(MultiOptionsC), C.POINTER(MultiModelC), vp, vp, C.c_int, C.c_int, vp, vp, vp, vp],
         "dartk_noobs_optimize_poses": [vp, C.POINTER(NoObsOptions), C.c_int, vp, vp, vp, vp, vp, vp],
         "dartk_noobs_get_error": [vp, C.POINTER(NoObsOptions), C.c_int, vp, vp, vp, vp],
         "dartk_profile_begin": [],

@@ -194,10 +194,28 @@ static int launch_self(const float *d_sites, int nSites, int fullDims, int redDi
     return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
 }
 
+// d_T_ds_sd: [T_ds | T_sd] (24 floats) on the device
+template <int RED>
+static int launch_inter_dev(const float *d_sites, int nSites, int fullDims, int redDims, const float *d_T_ds_sd,
+                            Model *src, Model *dst, const float *d_A, const int *d_map, float *d_result, hipStream_t st);
+
 template <int RED>
 static int launch_inter(const float *d_sites, int nSites, int fullDims, int redDims, const float *h_T_ds,
                         const float *h_T_sd, Model *src, Model *dst, const float *d_A, const int *d_map,
                         float *d_result, hipStream_t st) {
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    float hT[24];
+    for (int i = 0; i < 12; ++i) { hT[i] = h_T_ds[i]; hT[12 + i] = h_T_sd[i]; }
+    DARTK_HIP(hipMemcpyAsync(ws->sysScratch + 64, hT, sizeof(hT), hipMemcpyHostToDevice, st));
+    DARTK_HIP(hipStreamSynchronize(st));
+    return launch_inter_dev<RED>(d_sites, nSites, fullDims, redDims, ws->sysScratch + 64, src, dst, d_A, d_map, d_result, st);
+}
+
+template <int RED>
+static int launch_inter_dev(const float *d_sites, int nSites, int fullDims, int redDims, const float *d_T_ds_sd,
+                            Model *src, Model *dst, const float *d_A, const int *d_map, float *d_result, hipStream_t st) {
     const ModelView &ms = src->v;
     const ModelView &md = dst->v;
     DARTK_REQUIRE(fullDims == 6 + ms.nJoints, "dims %d does not match the source model's 6+%d", fullDims, ms.nJoints);
@@ -208,10 +226,6 @@ static int launch_inter(const float *d_sites, int nSites, int fullDims, int redD
     int rc = get_workspace(&ws);
     if (rc) return rc;
     if (nSites == 0) { DARTK_HIP(hipMemsetAsync(d_result, 0, S * sizeof(float), st)); return DARTK_OK; }
-    float hT[24];
-    for (int i = 0; i < 12; ++i) { hT[i] = h_T_ds[i]; hT[12 + i] = h_T_sd[i]; }
-    DARTK_HIP(hipMemcpyAsync(ws->sysScratch + 64, hT, sizeof(hT), hipMemcpyHostToDevice, st));
-    DARTK_HIP(hipStreamSynchronize(st));
     const int nTiles = (nSites + NE_BLOCK - 1) / NE_BLOCK;
     const int nBlocks = nTiles < kMaxPartialBlocks ? nTiles : kMaxPartialBlocks;
     rc = ensure_partials(ws, (size_t)nBlocks * S);
@@ -226,7 +240,7 @@ static int launch_inter(const float *d_sites, int nSites, int fullDims, int redD
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
         hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, ms, md,   \
-                           ws->sysScratch + 64, redDims, d_A, d_map, ws->partials);                             \
+                           d_T_ds_sd, redDims, d_A, d_map, ws->partials);                                       \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_INTER(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_INTER(6);
@@ -234,6 +248,31 @@ static int launch_inter(const float *d_sites, int nSites, int fullDims, int redD
 #undef DARTK_LAUNCH_INTER
     DARTK_HIP(hipGetLastError());
     return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
+}
+
+// T_ds = T_mc(dst) * T_cm(src) and its inverse from the models' device poses (optimizer.cpp:396-397)
+__global__ void pair_transform_kernel(ModelView src, ModelView dst, float *__restrict__ out24) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float A[12], B[12], T_ds[12], T_sd[12];
+    for (int i = 0; i < 12; ++i) { A[i] = dst.T_mc[i]; B[i] = src.T_cm[i]; }
+    se3_mul(A, B, T_ds);
+    se3_invert(T_ds, T_sd);
+    for (int i = 0; i < 12; ++i) { out24[i] = T_ds[i]; out24[12 + i] = T_sd[i]; }
+}
+
+// whole terms (kernel + reduction into d_result) for the device-resident multi-model loop; red: 0 full, 1 linear, 2 map
+int gn_ne_self_any(int red, const float *d_sites, int nSites, int fullDims, int redDims, Model *mod, const float *d_A,
+                   const int *d_map, const int *d_pot, float *d_result, hipStream_t st) {
+    if (red == 1) return launch_self<1>(d_sites, nSites, fullDims, redDims, mod, d_A, nullptr, d_pot, d_result, st);
+    if (red == 2) return launch_self<2>(d_sites, nSites, fullDims, redDims, mod, nullptr, d_map, d_pot, d_result, st);
+    return launch_self<0>(d_sites, nSites, fullDims, fullDims, mod, nullptr, nullptr, d_pot, d_result, st);
+}
+int gn_ne_inter_any(int red, const float *d_sites, int nSites, int fullDims, int redDims, Model *src, Model *dst,
+                    const float *d_A, const int *d_map, float *d_T_scratch24, float *d_result, hipStream_t st) {
+    hipLaunchKernelGGL(pair_transform_kernel, dim3(1), dim3(64), 0, st, src->v, dst->v, d_T_scratch24);
+    if (red == 1) return launch_inter_dev<1>(d_sites, nSites, fullDims, redDims, d_T_scratch24, src, dst, d_A, nullptr, d_result, st);
+    if (red == 2) return launch_inter_dev<2>(d_sites, nSites, fullDims, redDims, d_T_scratch24, src, dst, nullptr, d_map, d_result, st);
+    return launch_inter_dev<0>(d_sites, nSites, fullDims, fullDims, d_T_scratch24, src, dst, nullptr, nullptr, d_result, st);
 }
 
 // entry point for the device-resident Gauss-Newton loops: kernel only, slabs chosen by the caller

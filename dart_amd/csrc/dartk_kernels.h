@@ -26,6 +26,20 @@ int gn_launch_ne_mod2obs(const float *d_pred, int width, int height, const Model
 int gn_launch_ne_self(const float *d_sites, int nSites, const ModelView &m, const int *d_pot, float *slabs, int nBlocks,
                       hipStream_t st);
 
+// whole terms for the device-resident multi-model loop (dartk_multi.hip); red: 0 full pose, 1 linear reduction, 2 parameter map
+int gn_launch_ne_obs2mod_dev(int red, int fullDims, int redDims, const float *d_vert, Model *mod, float huberDelta,
+                             const dartk_da_point *d_pts, const int *d_count, int maxElements, const float *d_A,
+                             const int *d_map, float *d_result, hipStream_t st);
+int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr, const float *planeOffset, const float *pn3,
+                           dartk_da_point *const *pts, void **d_args_out, hipStream_t st);
+int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void *d_args, int *d_last, hipStream_t st);
+int gn_ne_mod2obs_any(int red, int fullDims, int redDims, const float *d_pred, int width, int height, Model *mod,
+                      const float *d_T_gc, const float *d_A, const int *d_map, float *d_result, int *d_num, hipStream_t st);
+int gn_ne_self_any(int red, const float *d_sites, int nSites, int fullDims, int redDims, Model *mod, const float *d_A,
+                   const int *d_map, const int *d_pot, float *d_result, hipStream_t st);
+int gn_ne_inter_any(int red, const float *d_sites, int nSites, int fullDims, int redDims, Model *src, Model *dst,
+                    const float *d_A, const int *d_map, float *d_T_scratch24, float *d_result, hipStream_t st);
+
 // optional per-kernel-class timing with HIP events on the launch stream (dartk_profile_begin / _end)
 int prof_push(int cls, hipStream_t st);       // returns an event-pair index or -1 when profiling is off
 void prof_pop(int idx, hipStream_t st);

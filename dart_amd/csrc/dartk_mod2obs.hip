@@ -537,6 +537,14 @@ static int launch_ne_mod2obs(int fullDims, int redDims, const float *d_pred, int
     return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
 }
 
+// whole term (kernel + reduction into d_result) for the device-resident multi-model loop; red: 0 full, 1 linear, 2 map
+int gn_ne_mod2obs_any(int red, int fullDims, int redDims, const float *d_pred, int width, int height, Model *mod,
+                      const float *d_T_gc, const float *d_A, const int *d_map, float *d_result, int *d_num, hipStream_t st) {
+    if (red == 1) return launch_ne_mod2obs<1, false>(fullDims, redDims, d_pred, width, height, mod, d_T_gc, 0.f, d_A, nullptr, d_result, d_num, false, st);
+    if (red == 2) return launch_ne_mod2obs<2, false>(fullDims, redDims, d_pred, width, height, mod, d_T_gc, 0.f, nullptr, d_map, d_result, d_num, false, st);
+    return launch_ne_mod2obs<0, false>(fullDims, fullDims, d_pred, width, height, mod, d_T_gc, 0.f, nullptr, nullptr, d_result, d_num, false, st);
+}
+
 // entry points for the device-resident Gauss-Newton loop (dartk_gn.hip)
 int gn_launch_ne_mod2obs(const float *d_pred, int width, int height, const ModelView &m, const float *d_T_gc,
                          float *slabs, int nBlocks, int *d_num, hipStream_t st) {

@@ -93,19 +93,50 @@ int ensure_valid_idx(Workspace *w, size_t ints) {
     return DARTK_OK;
 }
 
-__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int nBlocks, int S, float *__restrict__ result,
-                                    int keep) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= S) return;
+// 1024 threads = 32 outputs x 32 segments: segment g sums slabs g, g+32, ... in fp64 (fixed order), the 32 segment
+// sums are then added in segment order by the first 32 threads; a wave reads two 128-byte rows per step
+static constexpr int kReduceOuts = 32;
+static constexpr int kReduceSegs = 32;
+
+__global__ void __launch_bounds__(kReduceOuts * kReduceSegs)
+reduce_slabs_kernel(const float *__restrict__ slabs, int nBlocks, int S, float *__restrict__ result, int keep,
+                    const int *__restrict__ count, int minCount) {
+    __shared__ double part[kReduceSegs][kReduceOuts + 1];
+    const int col = threadIdx.x % kReduceOuts, seg = threadIdx.x / kReduceOuts;
+    const int o = blockIdx.x * kReduceOuts + col;
+    if (count) keep = *count > minCount;
     double s = 0.0;
-    if (keep) {
-        for (int b = 0; b < nBlocks; ++b) s += (double)slabs[(size_t)b * S + o];
+    if (keep && o < S) {
+        int b = seg;
+        for (; b + 3 * kReduceSegs < nBlocks; b += 4 * kReduceSegs) {
+            const float v0 = slabs[(size_t)b * S + o];
+            const float v1 = slabs[(size_t)(b + kReduceSegs) * S + o];
+            const float v2 = slabs[(size_t)(b + 2 * kReduceSegs) * S + o];
+            const float v3 = slabs[(size_t)(b + 3 * kReduceSegs) * S + o];
+            s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+        }
+        for (; b < nBlocks; b += kReduceSegs) s += (double)slabs[(size_t)b * S + o];
     }
-    result[o] = (float)s;
+    part[seg][col] = s;
+    __syncthreads();
+    if (seg == 0 && o < S) {
+        double t = 0.0;
+        for (int g = 0; g < kReduceSegs; ++g) t += part[g][col];
+        result[o] = (float)t;
+    }
 }
 
 int launch_reduce_slabs(const float *slabs, int nBlocks, int S, float *result, int keep, hipStream_t stream) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((S + 127) / 128), dim3(128), 0, stream, slabs, nBlocks, S, result, keep);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((S + kReduceOuts - 1) / kReduceOuts), dim3(kReduceOuts * kReduceSegs), 0,
+                       stream, slabs, nBlocks, S, result, keep, (const int *)nullptr, 0);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
+int launch_reduce_slabs_gated(const float *slabs, int nBlocks, int S, float *result, const int *d_count, int minCount,
+                              hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((S + kReduceOuts - 1) / kReduceOuts), dim3(kReduceOuts * kReduceSegs), 0,
+                       stream, slabs, nBlocks, S, result, 0, d_count, minCount);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }

@@ -1,0 +1,365 @@
+// dartk_multi.hip -- Optimizer::optimizePoses (optimizer.cpp:524-781), device-resident: multi-model tracking with
+// observations and (optionally) reduced poses. The reference drives every term from the host with one blocking
+// device->host copy per term, assembles and solves in Eigen, and uploads every pose again; here one call enqueues all
+// iterations: the terms leave their packed systems in HBM, one wave assembles the block system in the reference's order,
+// applies regularisation + LM scaling, runs the reference's upper-triangular back substitution (SURVEY A-1), updates the
+// reduced poses with their limits, projects them to full joint vectors and runs forward kinematics. No host round trip.
+#include "dartk_internal.h"
+#include "dartk_reduce.h"
+#include "dartk_kernels.h"
+#include "dartk_fk.h"
+
+#include <string.h>
+#include <vector>
+
+namespace dartk {
+
+struct MultiSolveModel {
+    ModelView v;
+    int redType, redArt, dims, off;         // dims = 6 + redArt; off = offset in the global system
+    const float *A;                         // linear reduction: [nJoints][redArt]
+    const int *map;                         // parameter map: [nJoints]
+    const float *b, *redMin, *redMax;       // device copies
+    float *redArtPtr;                       // [redArt] reduced articulation (device, in/out)
+    const float *sysA, *sysB, *sysC;        // packed systems of this iteration (null = term off)
+    const float *sysI[DARTK_MAX_MODELS];
+    float lamSelf, lamI[DARTK_MAX_MODELS];
+    const int *countA, *countB;
+    float reg, regScaled;
+};
+struct MultiSolveArgs {
+    int nModels, D, numIterations;
+    float lambdaA, lambdaB;
+    float *iterInfo;        // [numIterations][nModels][8] or null
+    float *firstSystem;     // [D*D + D] or null
+    MultiSolveModel m[DARTK_MAX_MODELS];
+};
+
+__device__ __forceinline__ void wave_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Optimizer::unpack (optimizer.cpp:50-70) into the model's block: eJ += lam*J^T e; upper J(i,j) += lam*packed[j(j+1)/2+i]
+__device__ __forceinline__ void unpack_block(float *J, int ld, float *eJ, const float *__restrict__ sys, float lam, int dims, int shift) {
+    const int lane = threadIdx.x & 63;
+    const int d = dims - shift;             // shift = 6: articulation-only system into the bottom-right block
+    for (int idx = lane; idx < d * d; idx += 64) {
+        const int i = idx / d, j = idx - i * d;
+        if (j < i) continue;
+        float t = 0.0f;
+        t += lam * sys[d + ((j * (j + 1)) >> 1) + i];
+        J[(shift + i) * ld + shift + j] += t;
+    }
+    for (int i = lane; i < d; i += 64) { float t = 0.0f; t += lam * sys[i]; eJ[shift + i] += t; }
+    wave_sync_lds();
+}
+
+__global__ void __launch_bounds__(64)
+multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration) {
+    extern __shared__ float lds[];
+    const MultiSolveArgs &a = *ap;
+    const int lane = threadIdx.x;
+    const int D = a.D;
+    const int ldU = (D + 1) | 1;
+    float *U = lds;                     // [D][ldU] upper triangle of the global system
+    float *bv = U + D * ldU;            // [D]
+    float *J = bv + D;                  // one model's block [dims][ldU]
+    float *eJ = J + D * ldU;            // [D]
+    float *ra = eJ + D;                 // reduced articulation of the model being updated [<= 64]
+    float *sT = ra + 64;                // forward-kinematics scratch
+    for (int i = lane; i < D * ldU; i += 64) U[i] = 0.0f;
+    for (int i = lane; i < D; i += 64) bv[i] = 0.0f;
+    wave_sync_lds();
+    for (int mi = 0; mi < a.nModels; ++mi) {
+        const MultiSolveModel &m = a.m[mi];
+        const int dims = m.dims, off = m.off;
+        for (int i = lane; i < dims * ldU; i += 64) J[i] = 0.0f;
+        for (int i = lane; i < dims; i += 64) eJ[i] = 0.0f;
+        wave_sync_lds();
+        float eA = 0.0f, eB = 0.0f, eI = 0.0f;
+        if (m.sysA) { unpack_block(J, ldU, eJ, m.sysA, a.lambdaA, dims, 0); eA = a.lambdaA * m.sysA[sys_size(dims) - 1]; }
+        if (m.sysB) { unpack_block(J, ldU, eJ, m.sysB, a.lambdaB, dims, 0); eB = a.lambdaB * m.sysB[sys_size(dims) - 1]; }
+        if (m.sysC) { unpack_block(J, ldU, eJ, m.sysC, m.lamSelf, dims, 6); eI = m.lamSelf * m.sysC[sys_size(dims - 6) - 1]; }
+        for (int d = 0; d < a.nModels; ++d)
+            if (m.sysI[d]) { unpack_block(J, ldU, eJ, m.sysI[d], m.lamI[d], dims, 0); eI = m.lamI[d] * m.sysI[d][sys_size(dims) - 1]; }
+        if (a.iterInfo && lane == 0) {      // e is assigned per term, the last one stays (SURVEY A-8)
+            float *r = a.iterInfo + ((size_t)iteration * a.nModels + mi) * 8;
+            r[0] = eA; r[1] = eB; r[2] = eI; r[3] = m.countA ? (float)*m.countA : 0.0f; r[4] = m.countB ? (float)*m.countB : 0.0f;
+            r[5] = r[6] = r[7] = 0.0f;
+        }
+        // regularisation, LM scaling (optimizer.cpp:695-700), then the upper triangle goes into the global system (:707-713)
+        for (int i = lane; i < dims; i += 64) {
+            float v = J[i * ldU + i];
+            v += m.reg * 1.0f;
+            v += m.regScaled * v;
+            J[i * ldU + i] = v;
+        }
+        wave_sync_lds();
+        for (int idx = lane; idx < dims * dims; idx += 64) {
+            const int i = idx / dims, j = idx - i * dims;
+            if (j >= i) U[(off + i) * ldU + off + j] = J[i * ldU + j];
+        }
+        for (int i = lane; i < dims; i += 64) bv[off + i] = eJ[i];
+        wave_sync_lds();
+    }
+    if (a.firstSystem && iteration == 0) {
+        for (int idx = lane; idx < D * D; idx += 64) a.firstSystem[idx] = U[(idx / D) * ldU + (idx % D)];
+        for (int i = lane; i < D; i += 64) a.firstSystem[D * D + i] = bv[i];
+    }
+    // paramUpdate = -U^-1 JTe by back substitution on the upper triangle (Eigen triangularView<Upper>().solve, :732:
+    // columns last to first, a column is skipped when its rhs entry is exactly 0)
+    float x = lane < D ? bv[lane] : 0.0f;       // D <= 64: lane r holds x[r]
+    for (int i = D - 1; i >= 0; --i) {
+        float xi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i));
+        if (xi != 0.0f) {
+            xi = xi / U[i * ldU + i];
+            if (lane == i) x = xi;
+            if (lane < i) {
+                const float u = U[lane * ldU + i];
+                if (u != 0.0f) x -= xi * u;
+            }
+        }
+    }
+    x = -x;
+    if (lane < D) bv[lane] = x;
+    wave_sync_lds();
+    // pose updates (:734-755), projection to the full joint vector, forward kinematics (Tracker::updatePose)
+    for (int mi = 0; mi < a.nModels; ++mi) {
+        const MultiSolveModel &m = a.m[mi];
+        const int off = m.off;
+        if (lane == 0) {
+            float t6[6], dT[12], T[12], Tn[12], Tinv[12];
+            for (int i = 0; i < 6; ++i) t6[i] = bv[off + i];
+            se3_exp(t6, dT);
+            for (int i = 0; i < 12; ++i) T[i] = m.v.T_mc[i];
+            se3_mul(dT, T, Tn);
+            se3_invert(Tn, Tinv);
+            for (int i = 0; i < 12; ++i) { m.v.T_mc[i] = Tn[i]; m.v.T_cm[i] = Tinv[i]; }
+        }
+        if (lane < m.redArt) {
+            const float v = m.redArtPtr[lane] + bv[off + 6 + lane];
+            const float c = fminf(fmaxf(m.redMin[lane], v), m.redMax[lane]);
+            m.redArtPtr[lane] = c;
+            ra[lane] = c;
+        }
+        wave_sync_lds();
+        if (lane < m.v.nJoints) {       // lane f writes joint f and is the lane that reads it back in fk_wave
+            float full;
+            if (m.redType == 0) full = ra[lane];
+            else if (m.redType == 2) full = ra[m.map[lane]];
+            else {
+                full = m.b[lane];
+                for (int r = 0; r < m.redArt; ++r) full = full + ra[r] * m.A[r + lane * m.redArt];      // pose.cpp:66-73
+            }
+            m.v.joints[lane] = full;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fk_wave(m.v, 0, sT);
+        wave_sync_lds();
+    }
+}
+
+// per-device buffers of the loop (argument block, per-term systems, small tables)
+struct MultiScratch { void *p; size_t bytes; };
+static MultiScratch g_multi[16];
+static int multi_scratch(size_t bytes, void **out) {
+    int dev = 0;
+    DARTK_HIP(hipGetDevice(&dev));
+    DARTK_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+    if (g_multi[dev].bytes < bytes) {
+        if (g_multi[dev].p) { DARTK_HIP(hipDeviceSynchronize()); DARTK_HIP(hipFree(g_multi[dev].p)); }
+        g_multi[dev].p = nullptr; g_multi[dev].bytes = 0;
+        DARTK_HIP(hipMalloc(&g_multi[dev].p, bytes));
+        g_multi[dev].bytes = bytes;
+    }
+    *out = g_multi[dev].p;
+    return DARTK_OK;
+}
+
+}  // namespace dartk
+
+using namespace dartk;
+
+extern "C" {
+
+int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *mm, const float *d_vert, const float *d_norm,
+                         int width, int height, float *d_prediction, float *d_iterInfo, float *d_firstSystem, void *stream) {
+    DARTK_REQUIRE(o && mm && d_vert && d_norm, "dartk_optimize_poses: null argument");
+    const int n = o->nModels;
+    DARTK_REQUIRE(n >= 1 && n <= DARTK_MAX_MODELS, "nModels %d out of range [1,%d]", n, DARTK_MAX_MODELS);
+    DARTK_REQUIRE(width > 0 && height > 0 && (long long)width * height < (1ll << 31), "bad map size %dx%d", width, height);
+    DARTK_REQUIRE(o->numIterations >= 0, "negative iteration count");
+    const bool useA = o->lambdaObsToMod > 0, useB = o->lambdaModToObs > 0;
+    if (useB) DARTK_REQUIRE(d_prediction && o->predWidth > 0 && o->predHeight > 0, "mod->obs term needs a prediction buffer");
+    hipStream_t st = as_stream(stream);
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+
+    static thread_local MultiSolveArgs h;
+    memset(&h, 0, sizeof(h));
+    Model *mods[DARTK_MAX_MODELS];
+    int D = 0, maxFrames = 1;
+    size_t tableFloats = 0, sysFloats = 0;
+    for (int m = 0; m < n; ++m) {
+        mods[m] = reinterpret_cast<Model *>(mm[m].model);
+        DARTK_REQUIRE(mods[m], "dartk_optimize_poses: null model %d", m);
+        const ModelView &v = mods[m]->v;
+        const int redArt = mm[m].redType == 0 ? v.nJoints : mm[m].redArtDims;
+        DARTK_REQUIRE(mm[m].redType >= 0 && mm[m].redType <= 2, "model %d: reduction type %d", m, mm[m].redType);
+        DARTK_REQUIRE(redArt >= 0 && redArt <= v.nJoints, "model %d: %d reduced dimensions for %d joints", m, redArt, v.nJoints);
+        DARTK_REQUIRE(mm[m].redType != 1 || mm[m].d_A, "model %d: linear reduction without its matrix", m);
+        DARTK_REQUIRE(mm[m].redType != 2 || mm[m].d_map, "model %d: parameter map without its mapping", m);
+        DARTK_REQUIRE(redArt == 0 || (mm[m].d_redArt && mm[m].h_redMin && mm[m].h_redMax), "model %d: reduced articulation / limits missing", m);
+        DARTK_REQUIRE(!useA || mm[m].d_pts, "model %d: association buffer missing", m);
+        DARTK_REQUIRE(!useB || mods[m]->obsVoxels > 0, "model %d has no observation SDF", m);
+        h.m[m].redType = mm[m].redType; h.m[m].redArt = redArt; h.m[m].dims = 6 + redArt; h.m[m].off = D;
+        D += 6 + redArt;
+        if (v.nFrames > maxFrames) maxFrames = v.nFrames;
+        tableFloats += (size_t)v.nJoints + 2 * (size_t)redArt + 12 + 24;     // b | min | max | T_obs | pair transform
+        sysFloats += (size_t)(2 + n) * sys_size(6 + redArt) + sys_size(redArt > 0 ? redArt : 1);
+    }
+    DARTK_REQUIRE(D <= 64, "global system dimension %d exceeds 64 (one lane per unknown in the solve)", D);
+    const size_t argBytes = (sizeof(MultiSolveArgs) + 255) / 256 * 256;
+    const size_t total = argBytes + sizeof(float) * (tableFloats + sysFloats) + sizeof(int) * 2 * DARTK_MAX_MODELS + 256;
+    void *base = nullptr;
+    rc = multi_scratch(total, &base);
+    if (rc) return rc;
+    MultiSolveArgs *d_args = reinterpret_cast<MultiSolveArgs *>(base);
+    int *d_countA = reinterpret_cast<int *>((char *)base + argBytes);
+    int *d_countB = d_countA + DARTK_MAX_MODELS;
+    float *fl = reinterpret_cast<float *>(d_countB + DARTK_MAX_MODELS);
+    std::vector<float> tables;
+    float *T_obs[DARTK_MAX_MODELS], *T_pair[DARTK_MAX_MODELS];
+    float *sysA[DARTK_MAX_MODELS], *sysB[DARTK_MAX_MODELS], *sysC[DARTK_MAX_MODELS], *sysI[DARTK_MAX_MODELS][DARTK_MAX_MODELS];
+    for (int m = 0; m < n; ++m) {
+        const ModelView &v = mods[m]->v;
+        MultiSolveModel &s = h.m[m];
+        const int redArt = s.redArt, S = sys_size(s.dims);
+        s.v = v;
+        s.A = mm[m].d_A; s.map = mm[m].d_map; s.redArtPtr = mm[m].d_redArt;
+        s.b = fl + tables.size();
+        for (int f = 0; f < v.nJoints; ++f) tables.push_back(mm[m].h_b ? mm[m].h_b[f] : 0.0f);
+        s.redMin = fl + tables.size();
+        for (int r = 0; r < redArt; ++r) tables.push_back(mm[m].h_redMin[r]);
+        s.redMax = fl + tables.size();
+        for (int r = 0; r < redArt; ++r) tables.push_back(mm[m].h_redMax[r]);
+        T_obs[m] = fl + tables.size(); tables.resize(tables.size() + 12, 0.0f);
+        T_pair[m] = fl + tables.size(); tables.resize(tables.size() + 24, 0.0f);
+        s.reg = mm[m].regularization; s.regScaled = mm[m].regularizationScaled;
+        s.countA = useA ? d_countA + m : nullptr;
+        s.countB = useB ? d_countB + m : nullptr;
+        (void)S;
+    }
+    float *sysBase = fl + tables.size();
+    size_t so = 0;
+    for (int m = 0; m < n; ++m) {
+        MultiSolveModel &s = h.m[m];
+        const int S = sys_size(s.dims);
+        sysA[m] = sysBase + so; so += S;
+        sysB[m] = sysBase + so; so += S;
+        sysC[m] = sysBase + so; so += sys_size(s.redArt > 0 ? s.redArt : 1);
+        for (int d = 0; d < n; ++d) { sysI[m][d] = sysBase + so; so += S; }
+        s.sysA = useA ? sysA[m] : nullptr;
+        s.sysB = useB ? sysB[m] : nullptr;
+        const float lamSelf = o->lambdaIntersection[m + m * n];
+        const bool useC = lamSelf > 0 && s.redArt > 0;
+        DARTK_REQUIRE(!useC || mm[m].nCloud == 0 || (mm[m].d_cloud && mm[m].d_potential), "model %d: self-intersection needs a cloud and a potential matrix", m);
+        s.sysC = useC ? sysC[m] : nullptr;
+        s.lamSelf = lamSelf;
+        for (int d = 0; d < n; ++d) {
+            const float lam = o->lambdaIntersection[m + d * n];
+            const bool on = d != m && lam > 0;
+            DARTK_REQUIRE(!on || mm[m].nCloud == 0 || mm[m].d_cloud, "model %d: intersection needs a collision cloud", m);
+            s.sysI[d] = on ? sysI[m][d] : nullptr;
+            s.lamI[d] = lam;
+        }
+    }
+    h.nModels = n; h.D = D; h.numIterations = o->numIterations;
+    h.lambdaA = o->lambdaObsToMod; h.lambdaB = o->lambdaModToObs;
+    h.iterInfo = d_iterInfo; h.firstSystem = d_firstSystem;
+    DARTK_HIP(hipMemcpyAsync(d_args, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    if (!tables.empty()) DARTK_HIP(hipMemcpyAsync(fl, tables.data(), sizeof(float) * tables.size(), hipMemcpyHostToDevice, st));
+    DARTK_HIP(hipStreamSynchronize(st));        // h and tables are host temporaries
+
+    // association argument block (pose arrays are updated in place, so once per call)
+    void *d_assocArgs = nullptr;
+    if (useA) {
+        float thr[DARTK_MAX_MODELS], po[DARTK_MAX_MODELS], pn[3 * DARTK_MAX_MODELS];
+        dartk_da_point *pts[DARTK_MAX_MODELS];
+        for (int m = 0; m < n; ++m) {
+            thr[m] = mm[m].distThreshold; po[m] = mm[m].planeOffset;
+            for (int k = 0; k < 3; ++k) pn[3 * m + k] = mm[m].planeNormal[k];
+            pts[m] = mm[m].d_pts;
+        }
+        rc = gn_assoc_multi_prepare(n, mods, thr, po, pn, pts, &d_assocArgs, st);
+        if (rc) return rc;
+    }
+    // generateObsSdf per model with its start pose (optimizer.cpp:574-580); the full-pose mod->obs wrapper works in that frame
+    if (useB) {
+        for (int m = 0; m < n; ++m) {
+            ProfScope ps(DARTK_PROF_OBS_SDF, st);
+            rc = gn_obs_sdf_build(d_vert, width, height, mods[m], o->focalLength, st);
+            if (rc) return rc;
+            DARTK_HIP(hipMemcpyAsync(T_obs[m], mods[m]->v.T_mc, 12 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+    }
+    const int ldU = (D + 1) | 1;
+    const size_t ldsSolve = sizeof(float) * ((size_t)2 * D * ldU + 2 * D + 64 + 12 * (size_t)maxFrames + 8);
+    DARTK_REQUIRE(ldsSolve <= 160 * 1024, "LDS requirement exceeds 160 KiB");
+    if (ldsSolve > 64 * 1024)
+        DARTK_HIP(hipFuncSetAttribute((const void *)multi_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
+    const int nPix = width * height;
+    for (int it = 0; it < o->numIterations; ++it) {
+        if (useB) {     // raytracePrediction of every model into one map + cullUnobservable (:610-618)
+            for (int m = 0; m < n; ++m) {
+                rc = gn_launch_raycast(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2), o->predWidth,
+                                       o->predHeight, m, mods[m]->v, d_prediction, st);
+                if (rc) return rc;
+            }
+            rc = gn_launch_cull(d_prediction, o->predWidth, o->predHeight, d_vert, width, height, st);
+            if (rc) return rc;
+            DARTK_HIP(hipMemsetAsync(d_countB, 0, n * sizeof(int), st));
+        }
+        if (useA) {
+            ProfScope ps(DARTK_PROF_OTHER, st);
+            rc = gn_assoc_multi_launch(d_vert, nPix, n, d_assocArgs, d_countA, st);
+            if (rc) return rc;
+        }
+        for (int m = 0; m < n; ++m) {
+            const MultiSolveModel &s = h.m[m];
+            const int fullDims = 6 + mods[m]->v.nJoints;
+            if (useA) {
+                ProfScope ps(DARTK_PROF_FUSED_OBS2MOD, st);
+                rc = gn_launch_ne_obs2mod_dev(s.redType, fullDims, s.dims, d_vert, mods[m], o->huberDelta, mm[m].d_pts, d_countA + m, nPix,
+                                              mm[m].d_A, mm[m].d_map, sysA[m], st);
+                if (rc) return rc;
+            }
+            if (useB) {     // reduced wrappers use the model's current T_mc, the full one T_obsSdf_c (modToObs.cu:851-988 vs :713-780)
+                ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
+                rc = gn_ne_mod2obs_any(s.redType, fullDims, s.dims, d_prediction, o->predWidth, o->predHeight, mods[m],
+                                       s.redType == 0 ? T_obs[m] : mods[m]->v.T_mc, mm[m].d_A, mm[m].d_map, sysB[m], d_countB + m, st);
+                if (rc) return rc;
+            }
+            if (s.sysC) {
+                ProfScope ps(DARTK_PROF_NE_SELF, st);
+                rc = gn_ne_self_any(s.redType, mm[m].d_cloud, mm[m].nCloud, fullDims, s.dims, mods[m], mm[m].d_A, mm[m].d_map,
+                                    mm[m].d_potential, sysC[m], st);
+                if (rc) return rc;
+            }
+            for (int d = 0; d < n; ++d) {
+                if (!s.sysI[d]) continue;
+                ProfScope ps(DARTK_PROF_NE_SELF, st);
+                rc = gn_ne_inter_any(s.redType, mm[m].d_cloud, mm[m].nCloud, fullDims, s.dims, mods[m], mods[d], mm[m].d_A, mm[m].d_map,
+                                     T_pair[m], sysI[m][d], st);
+                if (rc) return rc;
+            }
+        }
+        {
+            ProfScope ps(DARTK_PROF_SOLVE, st);
+            hipLaunchKernelGGL(multi_solve_kernel, dim3(1), dim3(64), ldsSolve, st, d_args, it);
+        }
+        DARTK_HIP(hipGetLastError());
+    }
+    return DARTK_OK;
+}
+
+}  // extern "C"

@@ -141,8 +141,9 @@ template <int PPT, int RED>
 __global__ void __launch_bounds__(NE_BLOCK)
 ne_obs2mod_kernel(const dartk_da_point *__restrict__ pts, const float4 *__restrict__ vert, int nPoints, ModelView m,
                   float huberDelta, int redDims, const float *__restrict__ dtheta_dalpha,
-                  const int *__restrict__ mapping, float *__restrict__ slabs) {
+                  const int *__restrict__ mapping, float *__restrict__ slabs, const int *__restrict__ d_count) {
     extern __shared__ float lds[];
+    if (d_count) nPoints = min(nPoints, *d_count);      // device-resident loops: the list length stays on the device
     const int fullDims = 6 + m.nJoints;
     const int d = RED ? redDims : fullDims;
     const bool drop = (RED != 0);
@@ -239,7 +240,7 @@ static int launch_ne_obs2mod(int fullDims, int redDims, const float *d_vert, Mod
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
         hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, nElements, m,         \
-                           huberDelta, redDims, d_A, d_map, ws->partials);                                      \
+                           huberDelta, redDims, d_A, d_map, ws->partials, (const int *)nullptr);                \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_NE(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_NE(6);
@@ -247,6 +248,79 @@ static int launch_ne_obs2mod(int fullDims, int redDims, const float *d_vert, Mod
 #undef DARTK_LAUNCH_NE
     DARTK_HIP(hipGetLastError());
     return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
+}
+
+// the same normal equations with the list length read on the device (*d_count, at most maxElements): a fixed grid walks
+// the tiles, and the "more than 10 elements" gate of the wrapper (obsToMod.cu:644-646) is applied by the reduction
+template <int RED>
+static int launch_ne_obs2mod_dev(int fullDims, int redDims, const float *d_vert, Model *mod, float huberDelta,
+                                 const dartk_da_point *d_pts, const int *d_count, int maxElements, const float *d_A,
+                                 const int *d_map, float *d_result, hipStream_t st) {
+    const ModelView &m = mod->v;
+    const int d = RED ? redDims : fullDims;
+    DARTK_REQUIRE(d >= 6 && d <= kMaxDims, "system dimension %d out of range [6,%d]", d, kMaxDims);
+    const int S = sys_size(d);
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    const int nTiles = (maxElements + NE_BLOCK - 1) / NE_BLOCK;
+    const int nBlocks = nTiles < 512 ? (nTiles > 0 ? nTiles : 1) : 512;
+    rc = ensure_partials(ws, (size_t)nBlocks * S);
+    if (rc) return rc;
+    const size_t ldsBytes = ne_obs2mod_lds_bytes(m, d, RED);
+    DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
+    const float4 *vert = reinterpret_cast<const float4 *>(d_vert);
+#define DARTK_LAUNCH_NE(PPT_)                                                                                   \
+    do {                                                                                                        \
+        auto kfn = ne_obs2mod_kernel<PPT_, RED>;                                                                \
+        if (ldsBytes > 64 * 1024)                                                                               \
+            DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, maxElements, m,       \
+                           huberDelta, redDims, d_A, d_map, ws->partials, d_count);                             \
+    } while (0)
+    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_NE(3);
+    else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_NE(6);
+    else DARTK_LAUNCH_NE(20);
+#undef DARTK_LAUNCH_NE
+    DARTK_HIP(hipGetLastError());
+    return launch_reduce_slabs_gated(ws->partials, nBlocks, S, d_result, d_count, 10, st);
+}
+
+int gn_launch_ne_obs2mod_dev(int red, int fullDims, int redDims, const float *d_vert, Model *mod, float huberDelta,
+                             const dartk_da_point *d_pts, const int *d_count, int maxElements, const float *d_A,
+                             const int *d_map, float *d_result, hipStream_t st) {
+    if (red == 1) return launch_ne_obs2mod_dev<1>(fullDims, redDims, d_vert, mod, huberDelta, d_pts, d_count, maxElements, d_A, nullptr, d_result, st);
+    if (red == 2) return launch_ne_obs2mod_dev<2>(fullDims, redDims, d_vert, mod, huberDelta, d_pts, d_count, maxElements, nullptr, d_map, d_result, st);
+    return launch_ne_obs2mod_dev<0>(fullDims, fullDims, d_vert, mod, huberDelta, d_pts, d_count, maxElements, nullptr, nullptr, d_result, st);
+}
+
+// multi-model association for the device-resident loop: the argument block is uploaded once per optimizePoses call
+// (the ModelViews point at pose arrays that are updated in place), then one launch per iteration
+int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr, const float *planeOffset, const float *pn3,
+                           dartk_da_point *const *pts, void **d_args_out, hipStream_t st) {
+    static thread_local MultiArgs hargs;
+    hargs.nModels = nModels;
+    for (int i = 0; i < nModels; ++i) {
+        hargs.m[i] = mods[i]->v;
+        hargs.distThr[i] = distThr[i];
+        hargs.planeOffset[i] = planeOffset[i];
+        for (int k = 0; k < 3; ++k) hargs.pn[i][k] = pn3[3 * i + k];
+        hargs.pts[i] = pts[i];
+    }
+    MultiArgs *d_args = nullptr;
+    int rc = get_multi_args_buffer((void **)&d_args, sizeof(MultiArgs));
+    if (rc) return rc;
+    DARTK_HIP(hipMemcpyAsync(d_args, &hargs, sizeof(MultiArgs), hipMemcpyHostToDevice, st));
+    DARTK_HIP(hipStreamSynchronize(st));   // hargs is reused by the next call
+    *d_args_out = d_args;
+    return DARTK_OK;
+}
+int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void *d_args, int *d_last, hipStream_t st) {
+    DARTK_HIP(hipMemsetAsync(d_last, 0, nModels * sizeof(int), st));
+    hipLaunchKernelGGL(assoc_multi_kernel<false>, dim3((nPix + 255) / 256), dim3(256), 0, st, (const float4 *)d_vert, nPix,
+                       (const MultiArgs *)d_args, d_last, nullptr, nullptr);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
 }
 
 }  // namespace dartk

@@ -246,12 +246,12 @@ __device__ __forceinline__ int compact_slot(bool active, int *waveCnt, int &tota
     return active ? off + __popcll(mask & lt) : -1;
 }
 
-// result[o] = scale * sum_b slabs[b][o], fixed order, fp64 accumulation. keep==0 writes zeros (the
-// reference's "nElements > 10" gate leaves the memset system untouched).
-__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int nBlocks, int S, float *__restrict__ result,
-                                    int keep);
-
+// result[o] = sum_b slabs[b][o] in a fixed order with fp64 accumulation. keep==0 writes zeros (the reference's
+// "nElements > 10" gate leaves the memset system untouched); the gated form reads that decision on the device
+// (*d_count > minCount).
 int launch_reduce_slabs(const float *slabs, int nBlocks, int S, float *result, int keep, hipStream_t stream);
+int launch_reduce_slabs_gated(const float *slabs, int nBlocks, int S, float *result, const int *d_count, int minCount,
+                              hipStream_t stream);
 
 #endif  // __HIPCC__
 

@@ -1,10 +1,11 @@
 """dart::Tracker + Optimizer::optimizePoses (src/tracker.{h,cpp}, src/optimization/optimizer.cpp:524-781) -- host mirror
 of the multi-model tracking loop with observations and (optionally) reduced poses.
 
-Round-1 form: the loop is driven from the host exactly as the reference drives it -- every term is one C-ABI call into
-libdartk (association, normal equations, intersection, ray-cast, obs-SDF), the packed systems come back with one copy
-per term, assembly / the triangular solve / the pose update run here in fp32 numpy following optimizer.cpp line by
-line. (The single-model and the NoObs loops are device-resident; this one is next)"""
+Two forms: optimizePosesDevice() hands the whole loop to libdartk (dartk_optimize_poses: terms, block assembly, the
+triangular solve, reduced pose updates, projection and forward kinematics stay on the device); optimizePoses() drives the
+loop from the host exactly as the reference does -- every term one C-ABI call (association, normal equations,
+intersection, ray-cast, obs-SDF), one copy back per term, assembly / solve / update in fp32 numpy following optimizer.cpp
+line by line. The second is the readable restatement the first is tested against."""
 import numpy as np
 import torch
 
@@ -115,7 +116,77 @@ class Tracker:
         p.projectReducedToFull()
         self.models[m].set_pose(p.getTransformCameraToModel(), p.getArticulation())
 
-    # ---- Optimizer::optimizePoses (optimizer.cpp:524-781)
+    # ---- Optimizer::optimizePoses (optimizer.cpp:524-781), device-resident (dartk_optimize_poses)
+    def optimizePosesDevice(self, vert, norm, debug=False):
+        """The whole loop in one library call: no host round trip per term or per iteration. Poses come back at the end."""
+        import ctypes as C
+        from . import _abi
+        from ._abi import check, lib
+        if self.priors:
+            raise NotImplementedError("priors in the observation loop are not wired up yet (device priors live in TrackerNoObs)")
+        o, n = self.opts, len(self.models)
+        dev = self.prediction.device
+        h, w = vert.shape[:2]
+        mm = (_abi.MultiModelC * n)()
+        keep = []
+        red_art = []
+        for m in range(n):
+            self.updatePose(m)
+            p, red = self.poses[m], self.red_dev[m]
+            ra_n = p.getReducedArticulatedDimensions()
+            ra = torch.from_numpy(np.ascontiguousarray(p.getReducedArticulation(), dtype=F).reshape(-1)[:ra_n].copy()).to(dev) if ra_n else \
+                torch.zeros(1, dtype=torch.float32, device=dev)
+            red_art.append(ra)
+            mins = np.asarray([p.getReducedMin(i) for i in range(ra_n)] or [0.0], dtype=F)
+            maxs = np.asarray([p.getReducedMax(i) for i in range(ra_n)] or [0.0], dtype=F)
+            b = np.ascontiguousarray(getattr(p._reduction, "_b", np.zeros(self.host_models[m].n_joints, dtype=F)), dtype=F)
+            if getattr(self, "_pts_dev", None) is None or len(self._pts_dev) != n or self._pts_dev[m].shape[0] < w * h:
+                self._pts_dev = [device.new_pts(w * h, dev) for _ in range(n)]
+            keep += [mins, maxs, b]
+            c = mm[m]
+            c.model = self.models[m].handle
+            c.redType = 0 if red is None else (2 if red[0] == "map" else 1)
+            c.redArtDims = ra_n
+            c.d_A = device._ptr(red[1]) if red is not None and red[0] == "linear" else None
+            c.d_map = device._ptr(red[1]) if red is not None and red[0] == "map" else None
+            c.h_b, c.h_redMin, c.h_redMax = _abi.fptr(b), _abi.fptr(mins), _abi.fptr(maxs)
+            c.d_redArt = device._ptr(ra)
+            c.d_cloud, c.nCloud = device._ptr(self.clouds[m]), int(self.clouds[m].shape[0])
+            c.d_potential = device._ptr(self.potentials[m])
+            c.d_pts = device._ptr(self._pts_dev[m])
+            c.distThreshold, c.planeOffset = float(o.distThreshold[m]), float(o.planeOffset[m])
+            for k in range(3):
+                c.planeNormal[k] = float(o.planeNormal[m][k])
+            c.regularization, c.regularizationScaled = float(o.regularization[m]), float(o.regularizationScaled[m])
+        mo = _abi.MultiOptionsC()
+        mo.numIterations, mo.nModels = int(o.numIterations), n
+        mo.lambdaObsToMod, mo.lambdaModToObs = float(o.lambdaObsToMod), float(o.lambdaModToObs)
+        mo.huberDelta, mo.focalLength = float(o.huberDelta), float(o.focalLength)
+        mo.predWidth, mo.predHeight = self.pred_width, self.pred_height
+        mo.predFl[0], mo.predFl[1] = float(self.pred_fl[0]), float(self.pred_fl[1])
+        for i in range(n * n):
+            mo.lambdaIntersection[i] = float(o.lambdaIntersection[i])
+        D = int(sum(p.getReducedDimensions() for p in self.poses))
+        info = first = None
+        if debug:
+            info = torch.zeros((max(o.numIterations, 1), n, 8), dtype=torch.float32, device=dev)
+            first = torch.zeros(D * D + D, dtype=torch.float32, device=dev)
+        check(lib().dartk_optimize_poses(C.byref(mo), mm, device._ptr(vert), device._ptr(norm), w, h, device._ptr(self.prediction),
+                                         device._ptr(info), device._ptr(first), device._stream()))
+        for m in range(n):      # the poses live on the device during the loop; mirror them back once
+            T_mc, _, _, _ = self.models[m].get_transforms()
+            p = self.poses[m]
+            p.setTransformCameraToModel(T_mc)
+            ra_n = p.getReducedArticulatedDimensions()
+            if ra_n:
+                p.getReducedArticulation()[:ra_n] = red_art[m].cpu().numpy()[:ra_n]
+            p.projectReducedToFull()
+        if debug:
+            self.iteration_summaries = info.cpu().numpy()
+            self.first_system = first.cpu().numpy()
+        return -1.0
+
+    # ---- Optimizer::optimizePoses (optimizer.cpp:524-781), host-driven: one C-ABI call per term as the reference drives it
     def optimizePoses(self, vert, norm, debug=False):
         if self.priors:
             raise NotImplementedError("priors in the observation loop are not wired up yet (device priors live in TrackerNoObs)")

@@ -282,6 +282,44 @@ int dartk_noobs_optimize_poses(dartk_noobs_t t, const dartk_noobs_options *opts,
 int dartk_noobs_get_error(dartk_noobs_t t, const dartk_noobs_options *opts, int batch, const float *d_T_mcs,
                           const float *d_joints, float *d_energy, void *stream);
 
+/* ------------------------------------------------------------------ multi-model tracking loop on the device */
+/* One model of Optimizer::optimizePoses (optimizer.cpp:524-781): its device mirror (pose already set and consistent with
+ * d_redArt), its pose reduction (pose.h: NullReduction / LinearPoseReduction / ParamMapPoseReduction), collision cloud,
+ * potential-intersection matrix, association list and per-model options (optimization.h:30-70). */
+typedef struct dartk_multi_model {
+    dartk_model_t model;
+    int32_t redType;            /* 0 null, 1 linear (full = b + A*reduced, pose.cpp:66-73), 2 parameter map (pose.cpp:91-97) */
+    int32_t redArtDims;         /* reduced articulation dimensions (ignored for type 0: the joint count) */
+    const float *d_A;           /* type 1: first derivatives [nJoints][redArtDims], device */
+    const int32_t *d_map;       /* type 2: mapping [nJoints], device */
+    const float *h_b;           /* type 1: offsets [nJoints], host (NULL = zeros) */
+    const float *h_redMin, *h_redMax;   /* [redArtDims] limits of the reduced articulation, host */
+    float *d_redArt;            /* [redArtDims] reduced articulation, device, in/out */
+    const float *d_cloud;       /* collision cloud [nCloud][4] (frame coordinates, .w = SDF number) or NULL */
+    int32_t nCloud;
+    const int32_t *d_potential; /* [nSdfs*nSdfs] or NULL */
+    dartk_da_point *d_pts;      /* association list, capacity width*height */
+    float distThreshold, planeOffset, planeNormal[3];
+    float regularization, regularizationScaled;
+} dartk_multi_model;
+typedef struct dartk_multi_options {
+    int32_t numIterations, nModels;
+    float lambdaObsToMod, lambdaModToObs, huberDelta, focalLength;
+    int32_t predWidth, predHeight;
+    float predFl[2];
+    float lambdaIntersection[DARTK_MAX_MODELS * DARTK_MAX_MODELS];      /* [src + dst*nModels] */
+} dartk_multi_options;
+/* Optimizer::optimizePoses (optimizer.h:86-110 / optimizer.cpp:524-781) without priors, device-resident: per iteration the
+ * ray-cast of every model + cullUnobservable, the multi-model association, per model obs->mod / mod->obs / self- and
+ * pairwise intersection normal equations in the pose's reduced dimensions, the block assembly with regularisation and LM
+ * scaling, the upper-triangular back substitution, the reduced pose updates with their limits, the projection to full joints
+ * and forward kinematics. The models' device poses and d_redArt hold the result. Optional d_iterInfo
+ * [numIterations][nModels][8] = {lambda*e obs->mod, mod->obs, last intersection term, #associated, #predicted, 0..};
+ * d_firstSystem [D*D + D] = upper JTJ and JTe of iteration 0 after regularisation, D = sum of reduced dims (<= 64). */
+int dartk_optimize_poses(const dartk_multi_options *opts, const dartk_multi_model *models, const float *d_vert,
+                         const float *d_norm, int width, int height, float *d_prediction, float *d_iterInfo,
+                         float *d_firstSystem, void *stream);
+
 /* ------------------------------------------------------------------ measurement (no reference counterpart) */
 /* Per-kernel-class device time of the Gauss-Newton loops, measured with HIP events recorded on the launch stream
  * around every launch between dartk_profile_begin() and dartk_profile_end(). Used by bench.py's roofline leg;

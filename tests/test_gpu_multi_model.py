@@ -84,3 +84,37 @@ def test_config5_moves_towards_truth_and_respects_reduced_limits(gpu):
 def test_config5_full_resolution(gpu):
     """BASELINE config 5 at its full 1280x720: counts and first system against the oracle, 2 iterations."""
     check(*run(1280, 720, 2), strict_iters=1)
+
+
+def test_device_loop_matches_host_driven_loop_and_oracle(gpu):
+    """dartk_optimize_poses (whole loop on the device) vs the host-driven loop over the same term kernels and vs the oracle.
+    The association lists are appended with atomics (as in the reference), so sums differ in order: agreement to rounding."""
+    iters = 4
+    sc, tr, vert, norm = setup(320, 180, iters)
+    tr.optimizePoses(vert, norm, debug=True)
+    host_T = [tr.getPose(m).getTransformCameraToModel().copy() for m in range(2)]
+    host_a = [tr.getPose(m).getReducedArticulation().copy() for m in range(2)]
+    host_info, host_first = tr.iteration_summaries.copy(), tr.first_system.copy()
+    for m, (T, a) in enumerate(sc.init):
+        tr.getPose(m).setTransformCameraToModel(T)
+        tr.getPose(m).getReducedArticulation()[:] = a
+    tr.optimizePosesDevice(vert, norm, debug=True)
+    D = 16
+    for sl in (slice(0, D * D), slice(D * D, D * D + D)):
+        nref = np.linalg.norm(host_first[sl].astype(np.float64))
+        assert np.linalg.norm(tr.first_system[sl].astype(np.float64) - host_first[sl]) / nref < 1e-5
+    assert np.array_equal(tr.iteration_summaries[0, :, 3:5], host_info[0, :, 3:5])
+    assert np.allclose(tr.iteration_summaries[0, :, :3], host_info[0, :, :3], rtol=1e-4, atol=1e-7)
+    same_counts = np.array_equal(tr.iteration_summaries[:, :, 3:5], host_info[:, :, 3:5])
+    for m in range(2):
+        dt, dr = pose_diff(tr.getPose(m).getTransformCameraToModel(), host_T[m])
+        da = float(np.abs(tr.getPose(m).getReducedArticulation() - host_a[m]).max()) if len(host_a[m]) else 0.0
+        print("model %d device loop vs host loop: |dt|=%.2e |dr|=%.2e max|dq_red|=%.2e (counts equal: %s)" % (m, dt, dr, da, same_counts))
+        bar = 1e-4 if same_counts else 5e-3
+        assert dt < bar and dr < 10 * bar and da < 10 * bar
+    # and the oracle
+    oT, oa, oinfo, ofirst = O.optimize_poses(tr, vert.cpu().numpy(), norm.cpu().numpy(), [T for T, _ in sc.init], [a for _, a in sc.init])
+    check(sc, tr, oT, oa, oinfo, ofirst, strict_iters=1)
+    # the full joint vector on the device is the projection of the reduced one (Barrett: 8 joints from 4)
+    _, _, _, joints = tr.models[0].get_transforms()
+    assert np.allclose(joints, tr.getPose(0).getArticulation(), atol=1e-6)
