@@ -703,13 +703,16 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     // The mod->obs chain (obs-SDF build, ray-cast, normal equations) and the obs->mod chain (valid-pixel compaction,
     // fused association + normal equations) only meet in the solve: with both terms on they run on two streams,
     // forked after the pose is final and joined before the reduction (the reference overlaps its ray-cast and its
-    // association the same way, optimizer.cpp:610-639). Each chain alone leaves most of the chip idle.
+    // association the same way, optimizer.cpp:610-639). Each chain alone leaves most of the chip idle. The longer
+    // chain (ray-cast -> mod->obs) stays on the caller's stream with the reduction and the solve, so that the
+    // iteration's critical path never waits on a cross-stream event; the shorter obs->mod chain takes the side stream
+    // and has finished long before the join.
     const bool fork = useA && useB && o->numIterations > 0;
-    hipStream_t stB = fork ? ws->auxStream : st;
+    hipStream_t stB = st, stA = fork ? ws->auxStream : st;
     DARTK_HIP(hipMemsetAsync(ws->counters, 0, 2 * sizeof(int), st));      // before the fork; later iterations: zeroed by the solve kernel
     if (fork) {
         DARTK_HIP(hipEventRecord(ws->evFork, st));
-        DARTK_HIP(hipStreamWaitEvent(stB, ws->evFork, 0));
+        DARTK_HIP(hipStreamWaitEvent(stA, ws->evFork, 0));
     }
     if (useB) {
         {
@@ -726,31 +729,30 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         DARTK_HIP(hipFuncSetAttribute((const void *)gn_solve_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS));
 
     if (useA && o->numIterations > 0) {
-        ProfScope ps(DARTK_PROF_OTHER, st);
-        hipLaunchKernelGGL(valid_count_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, st, (const float4 *)d_vert, nPix, vcOffsets);
-        hipLaunchKernelGGL(valid_scan_kernel, dim3(1), dim3(1024), 0, st, vcOffsets, nVcBlocks, d_nValid);
-        hipLaunchKernelGGL(valid_write_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, st, (const float4 *)d_vert, nPix, vcOffsets, validIdx);
+        ProfScope ps(DARTK_PROF_OTHER, stA);
+        hipLaunchKernelGGL(valid_count_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, stA, (const float4 *)d_vert, nPix, vcOffsets);
+        hipLaunchKernelGGL(valid_scan_kernel, dim3(1), dim3(1024), 0, stA, vcOffsets, nVcBlocks, d_nValid);
+        hipLaunchKernelGGL(valid_write_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, stA, (const float4 *)d_vert, nPix, vcOffsets, validIdx);
         DARTK_HIP(hipGetLastError());
     }
     for (int it = 0; it < o->numIterations; ++it) {
         if (fork && it > 0) {       // the pose of this iteration is final on `st` (previous solve)
             DARTK_HIP(hipEventRecord(ws->evFork, st));
-            DARTK_HIP(hipStreamWaitEvent(stB, ws->evFork, 0));
+            DARTK_HIP(hipStreamWaitEvent(stA, ws->evFork, 0));
         }
         if (useB) {
             rc = gn_launch_raycast_ne_mod2obs(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2),
                                               o->predWidth, o->predHeight, 0, m, d_prediction, d_T_gc, slabsB, nBlocksB, cntB, stB);
             if (rc) return rc;
-            if (fork) DARTK_HIP(hipEventRecord(ws->evJoin, stB));
         }
         if (useA) {
-            ProfScope ps(DARTK_PROF_FUSED_OBS2MOD, st);
+            ProfScope ps(DARTK_PROF_FUSED_OBS2MOD, stA);
 #define DARTK_LAUNCH_FUSED(PPT_)                                                                                \
     do {                                                                                                        \
         auto kfn = fused_obs2mod_kernel<PPT_>;                                                                  \
         if (ldsA > 64 * 1024)                                                                                   \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA)); \
-        hipLaunchKernelGGL(kfn, dim3(nBlocksA), dim3(NE_BLOCK), ldsA, st, (const float4 *)d_vert, (const float4 *)d_norm, \
+        hipLaunchKernelGGL(kfn, dim3(nBlocksA), dim3(NE_BLOCK), ldsA, stA, (const float4 *)d_vert, (const float4 *)d_norm, \
                            validIdx, d_nValid, m, o->distThreshold, o->normThreshold, o->planeOffset, o->planeNormal[0],      \
                            o->planeNormal[1], o->planeNormal[2], o->huberDelta, slabsA, cntA);                  \
     } while (0)
@@ -761,11 +763,14 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
             DARTK_HIP(hipGetLastError());
         }
         if (useC) {
-            ProfScope ps(DARTK_PROF_NE_SELF, st);
-            rc = gn_launch_ne_self(d_cloud, nCloud, m, d_potential, slabsC, nBlocksC, st);
+            ProfScope ps(DARTK_PROF_NE_SELF, stA);
+            rc = gn_launch_ne_self(d_cloud, nCloud, m, d_potential, slabsC, nBlocksC, stA);
             if (rc) return rc;
         }
-        if (fork) DARTK_HIP(hipStreamWaitEvent(st, ws->evJoin, 0));
+        if (fork) {
+            DARTK_HIP(hipEventRecord(ws->evJoin, stA));
+            DARTK_HIP(hipStreamWaitEvent(st, ws->evJoin, 0));
+        }
         const int Sa = sys_size(d - 6);
         ReduceArgs ra = {};
         int nTerms = 0;
