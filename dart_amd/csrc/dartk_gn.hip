@@ -708,19 +708,21 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     // iteration's critical path never waits on a cross-stream event; the shorter obs->mod chain takes the side stream
     // and has finished long before the join.
     const bool fork = useA && useB && o->numIterations > 0;
-    hipStream_t stB = st, stA = fork ? ws->auxStream : st;
+    hipStream_t stB = st, stA = fork ? ws->auxStream : st, stO = fork ? ws->auxStream2 : st;
     DARTK_HIP(hipMemsetAsync(ws->counters, 0, 2 * sizeof(int), st));      // before the fork; later iterations: zeroed by the solve kernel
     if (fork) {
         DARTK_HIP(hipEventRecord(ws->evFork, st));
         DARTK_HIP(hipStreamWaitEvent(stA, ws->evFork, 0));
+        DARTK_HIP(hipStreamWaitEvent(stO, ws->evFork, 0));
     }
-    if (useB) {
+    if (useB) {     // the obs SDF is first read by iteration 0's mod->obs kernel: built on a third stream beside the ray-cast
         {
-            ProfScope ps(DARTK_PROF_OBS_SDF, stB);
-            rc = gn_obs_sdf_build(d_vert, width, height, mod, o->focalLength, stB);
+            ProfScope ps(DARTK_PROF_OBS_SDF, stO);
+            rc = gn_obs_sdf_build(d_vert, width, height, mod, o->focalLength, stO);
         }
         if (rc) return rc;
-        DARTK_HIP(hipMemcpyAsync(d_T_gc, m.T_mc, 12 * sizeof(float), hipMemcpyDeviceToDevice, stB));
+        DARTK_HIP(hipMemcpyAsync(d_T_gc, m.T_mc, 12 * sizeof(float), hipMemcpyDeviceToDevice, stO));
+        if (fork) DARTK_HIP(hipEventRecord(ws->evObs, stO));
     }
     const size_t ldsA = sizeof(float) * (24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8);
     const size_t ldsS = solve_lds_bytes(d, m.nFrames);
@@ -742,7 +744,8 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         }
         if (useB) {
             rc = gn_launch_raycast_ne_mod2obs(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2),
-                                              o->predWidth, o->predHeight, 0, m, d_prediction, d_T_gc, slabsB, nBlocksB, cntB, stB);
+                                              o->predWidth, o->predHeight, 0, m, d_prediction, d_T_gc, slabsB, nBlocksB, cntB, stB,
+                                              (fork && it == 0) ? ws->evObs : nullptr);
             if (rc) return rc;
         }
         if (useA) {

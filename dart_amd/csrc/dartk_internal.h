@@ -101,7 +101,8 @@ struct Workspace {
     int *validIdx;         // compacted indices of valid observation pixels + block offsets
     size_t validInts;
     hipStream_t auxStream; // second stream: the mod->obs chain runs beside the obs->mod chain (fork/join by events)
-    hipEvent_t evFork, evJoin;
+    hipStream_t auxStream2; // third stream: the per-call obs-SDF build runs beside the first ray-cast
+    hipEvent_t evFork, evJoin, evObs;
 };
 int get_workspace(Workspace **ws);
 static constexpr int kMaxPartialBlocks = 2048;

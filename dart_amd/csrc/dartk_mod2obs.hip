@@ -558,10 +558,14 @@ int gn_launch_raycast(float flx, float fly, float ppx, float ppy, int width, int
 // ray-cast + mod->obs normal equations of the same prediction: the trace kernel, then ONE kernel that replays each pixel's
 // traces (writing the prediction for the caller) and goes on with the pixel -- one launch less on the critical path
 int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
-                                 float *d_prediction, const float *d_T_gc, float *slabs, int nBlocks, int *d_num, hipStream_t st) {
+                                 float *d_prediction, const float *d_T_gc, float *slabs, int nBlocks, int *d_num, hipStream_t st,
+                                 hipEvent_t beforeNe) {
+    // beforeNe: an event the normal-equation kernel (the first reader of the obs SDF and of T_gc) waits for; the
+    // ray-cast needs neither and starts at once
     if (m.nSdfs > NE_BLOCK) {
         int rc = launch_raycast(flx, fly, ppx, ppy, width, height, modelNum, m, d_prediction, 0.0f, st);
         if (rc) return rc;
+        if (beforeNe) DARTK_HIP(hipStreamWaitEvent(st, beforeNe, 0));
         ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
         return gn_launch_ne_mod2obs(d_prediction, width, height, m, d_T_gc, slabs, nBlocks, d_num, st);
     }
@@ -570,6 +574,7 @@ int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int
     if (rc) return rc;
     rc = launch_raycast_trace(flx, fly, ppx, ppy, width, height, m, 0.0f, ws, st);
     if (rc) return rc;
+    if (beforeNe) DARTK_HIP(hipStreamWaitEvent(st, beforeNe, 0));
     const int d = 6 + m.nJoints, S = sys_size(d), nPix = width * height;
     const size_t ldsBytes = ne_mod2obs_lds_bytes(m, d, 0) + sizeof(float) * 24 * (size_t)m.nSdfs;
     DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);

@@ -43,6 +43,8 @@ int get_workspace(Workspace **out) {
         DARTK_HIP(hipStreamCreateWithFlags(&w.auxStream, hipStreamNonBlocking));
         DARTK_HIP(hipEventCreateWithFlags(&w.evFork, hipEventDisableTiming));
         DARTK_HIP(hipEventCreateWithFlags(&w.evJoin, hipEventDisableTiming));
+        DARTK_HIP(hipStreamCreateWithFlags(&w.auxStream2, hipStreamNonBlocking));
+        DARTK_HIP(hipEventCreateWithFlags(&w.evObs, hipEventDisableTiming));
         g_ws_ready[dev] = true;
     }
     *out = &g_ws[dev];
