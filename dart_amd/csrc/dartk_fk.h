@@ -48,63 +48,101 @@ __device__ inline void se3_exp(const float *p, float *out) {   // SE3Fromse3, SE
     out[8] = a * -wy + b * (wx * wz);      out[9] = a * wx + b * (wy * wz);       out[10] = 1 + b * (-wy * wy - wx * wx); out[11] = tz;
 }
 
-// Local transform of joint `joint` (frame joint+1) relative to its parent frame: T_pf * D(p).
+// The constant tables one lane needs for its joint / frame: loaded ahead of time (fk_prefetch) so that the loads
+// fly while the caller is still solving; nothing in them depends on the pose.
+struct FkTables {
+    float lo, hi, ax, ay, az, dh[4], P[12];
+    int type, parent;
+};
+
+__device__ inline FkTables fk_prefetch(const ModelView &m) {
+    const int lane = threadIdx.x & 63;
+    FkTables t;
+    if (lane + 1 < m.nFrames) {
+        t.lo = m.limits[2 * lane]; t.hi = m.limits[2 * lane + 1];
+        t.ax = m.jointAxis[3 * lane]; t.ay = m.jointAxis[3 * lane + 1]; t.az = m.jointAxis[3 * lane + 2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t.dh[i] = m.dh[4 * lane + i];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) t.P[i] = m.T_pf[12 * lane + i];
+        t.type = m.jointType[lane];
+        t.parent = m.frameParent[lane + 1];
+    } else {
+        t.lo = t.hi = t.ax = t.ay = t.az = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t.dh[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) t.P[i] = 0.0f;
+        t.type = 0; t.parent = 0;
+    }
+    return t;
+}
+
+// Local transform of a joint (frame joint+1) relative to its parent frame: T_pf * D(p), p = the joint value.
 // mode 0: setPose (GraspIt DH form, mirrored_model.cpp:196-213), 1: setArticulation (axis-angle, :165-166)
-__device__ inline void fk_local(const ModelView &m, int mode, int joint, float *T) {
-    const float p = fminf(fmaxf(m.limits[2 * joint], m.joints[joint]), m.limits[2 * joint + 1]);
-    const float ax = m.jointAxis[3 * joint], ay = m.jointAxis[3 * joint + 1], az = m.jointAxis[3 * joint + 2];
-    float D[12], P[12];
+__device__ inline void fk_local(const FkTables &t, int mode, float value, float *T) {
+    const float p = fminf(fmaxf(t.lo, value), t.hi);
+    float D[12];
     if (mode == 0) {
-        const float *dh = m.dh + 4 * joint;
-        if (m.jointType[joint] == 0) dh_graspit(dh[3] + p * az, dh[2], dh[0], dh[1] + p * ax, p * ay, D);
-        else                         dh_graspit(dh[3], dh[2] + p * az, dh[0] + p * ax, dh[1], p * ay, D);
+        if (t.type == 0) dh_graspit(t.dh[3] + p * t.az, t.dh[2], t.dh[0], t.dh[1] + p * t.ax, p * t.ay, D);
+        else             dh_graspit(t.dh[3], t.dh[2] + p * t.az, t.dh[0] + p * t.ax, t.dh[1], p * t.ay, D);
     } else {
         float t6[6] = {0, 0, 0, 0, 0, 0};
-        if (m.jointType[joint] == 0) { t6[3] = p * ax; t6[4] = p * ay; t6[5] = p * az; }
-        else                         { t6[0] = p * ax; t6[1] = p * ay; t6[2] = p * az; }
+        if (t.type == 0) { t6[3] = p * t.ax; t6[4] = p * t.ay; t6[5] = p * t.az; }
+        else             { t6[0] = p * t.ax; t6[1] = p * t.ay; t6[2] = p * t.az; }
         se3_exp(t6, D);
     }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) P[i] = m.T_pf[12 * joint + i];
-    se3_mul(P, D, T);
+    se3_mul(t.P, D, T);
 }
 
 // Forward kinematics by ONE wave (call with all 64 lanes of a wave; nFrames <= 65). Lane j owns joint j /
 // frame j+1: the trigonometry of all joints runs in parallel, then the chain products T_mf[f] = T_mf[parent]*T
 // are resolved level by level of the kinematic tree (depth <= 5 for the hands). Per frame the arithmetic is the
 // same sequence as the serial walk of the reference (mirrored_model.cpp:185-225), so results are identical.
-// `sT` = LDS scratch of 12*nFrames floats.
-__device__ inline void fk_wave(const ModelView &m, int mode, float *sT) {
+// `sT` = LDS scratch of 12*nFrames floats; `value` = this lane's joint value (lane j: joint j).
+__device__ inline void fk_wave(const ModelView &m, int mode, float *sT, const FkTables &t, float value) {
     const int lane = threadIdx.x & 63;
     const int f = lane + 1;
     const bool mine = f < m.nFrames;
     float T[12];
-    int depth = 0, parent = 0;
-    if (mine) {
-        fk_local(m, mode, lane, T);
-        parent = m.frameParent[f];
-        for (int q = f; q != 0; q = m.frameParent[q]) ++depth;
-    }
+    // depth of every frame: the parent table goes through LDS (borrowing sT), the walk up the tree reads LDS
+    int *sParent = reinterpret_cast<int *>(sT);
+    if (lane == 0) sParent[0] = 0;
+    if (mine) sParent[f] = t.parent;
+    if (mine) fk_local(t, mode, value, T);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int depth = 0;
+    if (mine)
+        for (int q = f; q != 0; q = sParent[q]) ++depth;
+    int maxDepth = depth;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxDepth = max(maxDepth, __shfl_xor(maxDepth, o));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every lane is done with sParent before sT is reused
     if (lane == 0) {
         const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
 #pragma unroll
         for (int i = 0; i < 12; ++i) { sT[i] = I[i]; m.T_mf[i] = I[i]; m.T_fm[i] = I[i]; }
     }
-    int maxDepth = depth;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxDepth = max(maxDepth, __shfl_xor(maxDepth, o));
     for (int level = 1; level <= maxDepth; ++level) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous level's LDS writes have landed
         if (mine && depth == level) {
             float P[12], R[12], Rinv[12];
 #pragma unroll
-            for (int i = 0; i < 12; ++i) P[i] = sT[12 * parent + i];
+            for (int i = 0; i < 12; ++i) P[i] = sT[12 * t.parent + i];
             se3_mul(P, T, R);
             se3_invert(R, Rinv);
 #pragma unroll
             for (int i = 0; i < 12; ++i) { sT[12 * f + i] = R[i]; m.T_mf[12 * f + i] = R[i]; m.T_fm[12 * f + i] = Rinv[i]; }
         }
     }
+}
+
+// the same with the tables and the joint values read here (m.joints must be visible to the calling lane)
+__device__ inline void fk_wave(const ModelView &m, int mode, float *sT) {
+    const int lane = threadIdx.x & 63;
+    const FkTables t = fk_prefetch(m);
+    const float value = (lane + 1 < m.nFrames) ? m.joints[lane] : 0.0f;
+    fk_wave(m, mode, sT, t, value);
 }
 
 #endif  // __HIPCC__

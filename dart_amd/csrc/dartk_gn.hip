@@ -557,6 +557,12 @@ gn_solve_single_kernel(ModelView m, SolveArgs a) {
 #ifdef DARTK_STAMPS
     const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    // everything the update and the forward kinematics read that does not depend on the solution is requested now
+    const FkTables fkT = fk_prefetch(m);
+    const float jointOld = tid < m.nJoints ? m.joints[tid] : 0.0f;
+    float Told[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Told[i] = m.T_mc[i];
 
     if (a.firstSystem) {
         for (int o = tid; o < S; o += 64) { a.firstSystem[o] = sysA ? sysA[o] : 0.0f; a.firstSystem[S + o] = sysB ? sysB[o] : 0.0f; }
@@ -602,20 +608,21 @@ gn_solve_single_kernel(ModelView m, SolveArgs a) {
     const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
 #endif
     if (tid == 0) {
-        float t6[6], dT[12], T[12], Tn[12], Tinv[12];
+        float t6[6], dT[12], Tn[12], Tinv[12];
         for (int i = 0; i < 6; ++i) t6[i] = -x[i];
         se3_exp(t6, dT);
-        for (int i = 0; i < 12; ++i) T[i] = m.T_mc[i];
-        se3_mul(dT, T, Tn);
+        se3_mul(dT, Told, Tn);
         se3_invert(Tn, Tinv);
         for (int i = 0; i < 12; ++i) { m.T_mc[i] = Tn[i]; m.T_cm[i] = Tinv[i]; }
     }
+    float jointNew = 0.0f;
     if (tid < m.nJoints) {
-        const float v = m.joints[tid] + (-x[6 + tid]);
-        m.joints[tid] = fminf(fmaxf(m.limits[2 * tid], v), m.limits[2 * tid + 1]);
+        const float v = jointOld + (-x[6 + tid]);
+        jointNew = fminf(fmaxf(fkT.lo, v), fkT.hi);
+        m.joints[tid] = jointNew;
     }
-    // forward kinematics for the next iteration (MirroredModel::setPose); lane j re-reads the joint it just wrote
-    fk_wave(m, 0, sT);
+    // forward kinematics for the next iteration (MirroredModel::setPose); lane j carries the joint it just wrote
+    fk_wave(m, 0, sT, fkT, jointNew);
 #ifdef DARTK_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
