@@ -167,6 +167,7 @@ def lib():
         "dartk_ne_intersection_parammap": [vp, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, vp, vp, vp, vp, vp],
         "dartk_count_self_intersections": [vp, C.c_int, vp, vp, c_int_p, vp],
         "dartk_count_intersections": [vp, C.c_int, c_float_p, vp, vp, c_int_p, vp],
+        "dartk_splat_solid_mesh": [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, vp, vp],
         "dartk_depth_to_vertices": [vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp],
         "dartk_vertices_to_normals": [vp, vp, C.c_int, C.c_int, vp],
         "dartk_prediction_to_depth": [vp, vp, C.c_int, C.c_int, vp],

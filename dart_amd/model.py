@@ -167,11 +167,21 @@ class HostModel:
                     corners = np.array([[sx * s[0], sy * s[1], szz * s[2]] for sx in (-1, 1) for sy in (-1, 1) for szz in (-1, 1)])
                     corners = corners @ R.T
                     o, sz = corners.min(axis=0), corners.max(axis=0)
+            elif g["type"] == GEOM_MESH:    # bounds of the scaled, transformed vertices (host_only_model.cpp:591-628)
+                lo, hi = self._geom_mesh(g).bounds()
+                o, sz = lo, (hi - lo).astype(F)
             else:
-                raise NotImplementedError("mesh geometry needs the mesh pipeline (SURVEY 8f-2); use a primitive proxy")
+                raise NotImplementedError("geometry type %r" % (g["type"],))
             mn = np.minimum(mn, np.asarray(o, dtype=F))
             mx = np.maximum(mx, np.asarray(o, dtype=F) + np.asarray(sz, dtype=F))
         return mn, mx
+
+    @staticmethod
+    def _geom_mesh(g):
+        """scaleMesh + transformMesh of a mesh geometry (host_only_model.cpp:593-601, 815-824)."""
+        if g.get("mesh") is None:
+            raise ValueError("mesh geometry without a loaded mesh (read_model_xml(..., load_meshes=True))")
+        return g["mesh"].scaled(g["scale"]).transformed(g["T"])
 
     def _occupancy(self, frame, resolution, padding):
         geoms = self.frame_geoms(frame)
@@ -183,6 +193,11 @@ class HostModel:
         occ = np.zeros((dim[2], dim[1], dim[0]), dtype=bool)
         res = F(resolution)
         for g in geoms:
+            if g["type"] == GEOM_MESH:      # splatSolidMesh writes the foreground value 0 (host_only_model.cpp:813-826)
+                from .mesh import splat_solid_mesh
+                data = splat_solid_mesh(self._geom_mesh(g), dim, mn, res, np.where(occ, F(0), F(1e20)).astype(F))
+                occ = data == 0
+                continue
             s = g["scale"].astype(F)
             t6 = se3.log(g["T"])
             c, w = t6[:3], t6[3:]
@@ -415,6 +430,11 @@ class HostModel:
                     local = (rng.random((n, 3)) - 0.5) * sc
                     sign = np.where(rng.random(n) < 0.5, -0.5, 0.5)
                     local[np.arange(n), face] = sign * sc[face]
+                elif g["type"] == GEOM_MESH:    # sampleMesh on the mesh as placed in the frame (tracker.cpp:143-210)
+                    from .mesh import sample_mesh, GlibcRand
+                    world = sample_mesh(self._geom_mesh(g), density, GlibcRand(1 + seed))
+                    pts.append(np.concatenate([world.astype(F), np.full((len(world), 1), s_num, dtype=F)], axis=1))
+                    continue
                 else:
                     continue
                 world = se3.apply(g["T"], local.astype(F))
@@ -456,10 +476,11 @@ class HostModel:
         return m
 
 
-def read_model_xml(path, mesh_proxy=None):
-    """readModelXML + readFrameXML (dart_io.cpp:15-159). Mesh geoms need the mesh pipeline; until
-    then `mesh_proxy(frame_index, geom_attrib_dict, model)` may return a list of primitive geometry specs
-    ({type, scale, trans, rot}) that stand in for the mesh, or None to drop it."""
+def read_model_xml(path, mesh_proxy=None, load_meshes=False):
+    """readModelXML + readFrameXML (dart_io.cpp:15-159). Mesh geoms: with `load_meshes` the file named by `meshFile`
+    (relative to the XML's directory) is read by dart_amd.mesh.read_mesh and voxelised / sampled by the mesh pipeline;
+    otherwise `mesh_proxy(frame_index, geom_attrib_dict, model)` may return a list of primitive geometry specs
+    ({type, scale, trans, rot}) that stand in for a mesh that is not available, or None to drop it."""
     root = ET.parse(path).getroot()
     if root.tag != "model":
         raise ValueError("expected 'model' at root node; got %r" % root.tag)
@@ -492,7 +513,12 @@ def read_model_xml(path, mesh_proxy=None):
                 gt = _GEOM_NAMES[a["type"]]
                 spec = {"frame": parent, "type": gt, "scale": [a["sx"], a["sy"], a["sz"]],
                         "trans": [a["tx"], a["ty"], a["tz"]], "rot": [a["rx"], a["ry"], a["rz"]]}
-                if gt == GEOM_MESH:
+                if gt == GEOM_MESH and load_meshes:
+                    from .mesh import read_mesh
+                    spec["mesh"] = read_mesh(os.path.join(os.path.dirname(os.path.abspath(path)), a["meshFile"]))
+                    spec["meshFile"] = a["meshFile"]
+                    specs.append(spec)
+                elif gt == GEOM_MESH:
                     repl = mesh_proxy(parent, dict(a), m) if mesh_proxy else None
                     for r in (repl or []):
                         r = dict(r); r["frame"] = parent
@@ -507,8 +533,9 @@ def read_model_xml(path, mesh_proxy=None):
         s["scale"] = [_safe_eval(v, m.params) for v in s["scale"]]
         s["trans"] = [_safe_eval(v, m.params) for v in s["trans"]]
         s["rot"] = [_safe_eval(v, m.params) for v in s["rot"]]
+        mesh = s.pop("mesh", None)
         norm.append(s)
-        m.add_geometry(s["frame"], s["type"], s["scale"], s["trans"], s["rot"])
+        m.add_geometry(s["frame"], s["type"], s["scale"], s["trans"], s["rot"], mesh=mesh)
     m._geom_specs = norm
     return m
 

@@ -179,6 +179,15 @@ int dartk_count_self_intersections(const float *d_sites, int nSites, dartk_model
 int dartk_count_intersections(const float *d_sites, int nSites, const float *h_T_ds, dartk_model_t src,
                               dartk_model_t dst, int32_t *h_count, void *stream);
 
+/* ---- model / asset pipeline: solid-mesh voxel splat (mesh/mesh_splat.cpp:10-265, splatSolidMesh) -------------------
+ * Sets d_sdf[x + y*dimX + z*dimX*dimY] = 0 for every voxel that at least two of the three axis-parallel parity ray
+ * casts find inside the triangle mesh (d_vertices: float[3*nVertices], d_faces: int32[3*nFaces], both in the grid's
+ * coordinate frame, i.e. after scaleMesh/transformMesh, host_only_model.cpp:813-826); other voxels are left as they
+ * are (the caller presets the background, 1e20 in HostOnlyModel::voxelize, host_only_model.cpp:290). Synchronises
+ * the stream before returning (its scratch is released). */
+int dartk_splat_solid_mesh(const float *d_vertices, int nVertices, const int32_t *d_faces, int nFaces, int dimX, int dimY,
+                           int dimZ, const float *h_offset /*[3]*/, float resolution, float *d_sdf, void *stream);
+
 /* ------------------------------------------------------------------ synthetic depth front end */
 /* depthToVertices<float> (img_proc/organized_point_cloud.h; .cu:11-40, :381-395): back-projection
  * ((u-pp.x)*z/f.x, (v-pp.y)*z/f.y, z, 1) for range.x <= z <= range.y, else w = 0. */

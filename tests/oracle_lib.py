@@ -421,3 +421,30 @@ def optimize_poses(tracker, vert, norm, T_mcs, arts):
     lib().orc_optimize_poses(models, T_ptrs, a_ptrs, reds, C.byref(mo), f(c32(vert)), f(c32(norm)), w, h, c_ptrs, counts, p_ptrs,
                              None, 0, obs_ptrs, f(info), f(first))
     return T_keep, [a_keep[m][:len(arts[m])] for m in range(n)], info, first
+
+
+# ---- mesh pipeline (oracle/mesh_oracle.c) -------------------------------------------------------------------------------
+def splat_solid_mesh(vertices, faces, dim, offset, resolution, data):
+    """orc_splat_solid_mesh: returns a copy of `data` ([z][y][x]) with 0 in the voxels the mesh fills."""
+    v = c32(vertices).reshape(-1, 3)
+    fc = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
+    d = np.asarray(dim, dtype=np.int32)
+    out = c32(data).copy()
+    rc = lib().orc_splat_solid_mesh(f(v), C.c_int(len(v)), i(fc), C.c_int(len(fc)), i(d), f(c32(offset)), C.c_float(float(F(resolution))), f(out))
+    assert rc == 0
+    return out
+
+
+def sample_mesh(vertices, faces, density, seed=1, max_points=1 << 22):
+    v = c32(vertices).reshape(-1, 3)
+    fc = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
+    out = np.zeros((max_points, 3), dtype=F)
+    n = lib().orc_sample_mesh(f(v), i(fc), C.c_int(len(fc)), C.c_float(float(F(density))), C.c_uint(seed), f(out), C.c_int(max_points))
+    assert n >= 0
+    return out[:n].copy()
+
+
+def libc_rand(seed, n):
+    out = np.zeros(n, dtype=np.int32)
+    lib().orc_libc_rand(C.c_uint(seed), C.c_int(n), i(out))
+    return out
