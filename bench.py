@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--grasp-candidates", type=int, default=4096)
     ap.add_argument("--grasp-steps", type=int, default=3)
     ap.add_argument("--no-grasps", action="store_true")
+    ap.add_argument("--no-multi-model", action="store_true", help="skip the config-5 (two-model tracking) leg")
+    ap.add_argument("--multi-steps", type=int, default=20)
     ap.add_argument("--no-tracking", action="store_true", help="profiling aid: skip the headline leg's timed loop")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="test aid for a 1-GPU box: every rank uses cuda:0 and the ranks talk over gloo (RCCL refuses two ranks on one device); "
@@ -327,6 +329,43 @@ def main():
                                            "(point, SDF) pair), not bandwidth bound: see DESIGN.md"},
                       "cpu_baseline": g_cpu}
 
+    # third leg: BASELINE configs[4] (Barrett 8->4 reduced + box object, 1280x720, multi-model tracking with observations):
+    # the device-resident Optimizer::optimizePoses loop, one independent frame per GPU (weak scaling), no collective
+    multi = None
+    if not args.no_multi_model:
+        from dart_amd.optimizer import synthetic_observation
+        m_iters = 10
+        msc = configs.config5(1280, 720, rank)
+        mtr = configs.make_multi_tracker(msc)
+        for m, (T, a) in enumerate(msc.true):
+            mtr.getPose(m).setTransformCameraToModel(T)
+            mtr.getPose(m).getReducedArticulation()[:] = a
+            mtr.updatePose(m)
+        _, mvert, mnorm = synthetic_observation(mtr.models, msc.width, msc.height, msc.fl, msc.pp)
+        mtr.getOptions().numIterations = m_iters
+
+        def mstep():
+            for m, (T, a) in enumerate(msc.init):
+                mtr.getPose(m).setTransformCameraToModel(T)
+                mtr.getPose(m).getReducedArticulation()[:] = a
+            mtr.optimizePosesDevice(mvert, mnorm)
+
+        for _ in range(2):
+            mstep()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.multi_steps):
+            mstep()
+        barrier()
+        m_elapsed = max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            multi = {"metric": "multi-model tracking (device-resident optimizePoses)", "unit": "GN iterations/s",
+                     "value": round(world * args.multi_steps * m_iters / m_elapsed, 2), "scaling": "weak", "steps": args.multi_steps,
+                     "ms_per_step": round(1000.0 * m_elapsed / args.multi_steps, 4), "iterations_per_step": m_iters,
+                     "config": {"workload": "BASELINE configs[4]: Barrett hand (8 joints reduced to 4, proxy geometry) + box object, "
+                                            "synthetic 1280x720 depth, obs->mod + mod->obs + self / pairwise intersection in reduced "
+                                            "dimensions, %d GN iterations per optimizePoses call incl. the pose reset; one frame per GPU" % m_iters}}
+
     if rank == 0:
         value = world * n_steps * iters / elapsed if n_steps else 0.0
         line = {
@@ -337,7 +376,7 @@ def main():
                                    "prediction 320x240, 64^3 obs SDF, obs->mod + mod->obs, %d GN iterations per optimizePose call, "
                                    "normThreshold %.1f; one frame per GPU" % (iters, sc.opts.normThreshold),
                        "iterations_per_step": iters, "frames_per_gpu": 1, "parallelism": "independent frames, 1 per GPU"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "batched_grasps": grasps,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "batched_grasps": grasps, "multi_model_tracking": multi,
         }
         print(json.dumps(line, default=float))
     if distributed:
