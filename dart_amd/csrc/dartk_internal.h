@@ -101,9 +101,13 @@ struct Workspace {
     int *validIdx;         // compacted indices of valid observation pixels + block offsets
     size_t validInts;
     hipStream_t auxStream; // second stream: the mod->obs chain runs beside the obs->mod chain (fork/join by events)
+    int partialLane;       // which third of `partials` the next term wrapper uses (device loops run three chains side by side)
     hipStream_t auxStream2; // third stream: the per-call obs-SDF build runs beside the first ray-cast
-    hipEvent_t evFork, evJoin, evObs;
+    hipEvent_t evFork, evJoin, evObs, evJoin2;
 };
+static constexpr int kPartialLanes = 3;
+// the slab buffer of the current lane; partialFloats is the capacity of ONE lane
+inline float *lane_partials(Workspace *w) { return w->partials + (size_t)w->partialLane * w->partialFloats; }
 int get_workspace(Workspace **ws);
 static constexpr int kMaxPartialBlocks = 2048;
 static constexpr int kMaxDims = 70;                       // 6 + DARTK_MAX_JOINTS

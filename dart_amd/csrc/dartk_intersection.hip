@@ -184,14 +184,14 @@ static int launch_self(const float *d_sites, int nSites, int fullDims, int redDi
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
         hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, m, d_pot, \
-                           redDims, d_A, d_map, ws->partials);                                                  \
+                           redDims, d_A, d_map, lane_partials(ws));                                                  \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_SELF(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_SELF(6);
     else DARTK_LAUNCH_SELF(20);
 #undef DARTK_LAUNCH_SELF
     DARTK_HIP(hipGetLastError());
-    return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
+    return launch_reduce_slabs(lane_partials(ws), nBlocks, S, d_result, 1, st);
 }
 
 // d_T_ds_sd: [T_ds | T_sd] (24 floats) on the device
@@ -240,14 +240,14 @@ static int launch_inter_dev(const float *d_sites, int nSites, int fullDims, int 
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
         hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, ms, md,   \
-                           d_T_ds_sd, redDims, d_A, d_map, ws->partials);                                       \
+                           d_T_ds_sd, redDims, d_A, d_map, lane_partials(ws));                                       \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_INTER(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_INTER(6);
     else DARTK_LAUNCH_INTER(20);
 #undef DARTK_LAUNCH_INTER
     DARTK_HIP(hipGetLastError());
-    return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
+    return launch_reduce_slabs(lane_partials(ws), nBlocks, S, d_result, 1, st);
 }
 
 // T_ds = T_mc(dst) * T_cm(src) and its inverse from the models' device poses (optimizer.cpp:396-397)

@@ -532,9 +532,9 @@ static int launch_ne_mod2obs(int fullDims, int redDims, const float *d_pred, int
     if (rc) return rc;
     if (zeroCounter) DARTK_HIP(hipMemsetAsync(d_num, 0, sizeof(int), st));
     rc = launch_ne_mod2obs_kernel<RED, TRUNC>(fullDims, redDims, d_pred, width, height, m, d_T_gc, trunc, d_A, d_map,
-                                              ws->partials, nBlocks, d_num, st);
+                                              lane_partials(ws), nBlocks, d_num, st);
     if (rc) return rc;
-    return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
+    return launch_reduce_slabs(lane_partials(ws), nBlocks, S, d_result, 1, st);
 }
 
 // whole term (kernel + reduction into d_result) for the device-resident multi-model loop; red: 0 full, 1 linear, 2 map

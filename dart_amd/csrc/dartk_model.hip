@@ -35,7 +35,8 @@ int get_workspace(Workspace **out) {
     if (!g_ws_ready[dev]) {
         Workspace &w = g_ws[dev];
         w.partialFloats = (size_t)kMaxPartialBlocks * 1024;   // grown on demand by ensure_partials
-        DARTK_HIP(hipMalloc((void **)&w.partials, w.partialFloats * sizeof(float)));
+        w.partialLane = 0;
+        DARTK_HIP(hipMalloc((void **)&w.partials, kPartialLanes * w.partialFloats * sizeof(float)));
         DARTK_HIP(hipMalloc((void **)&w.counters, 64 * sizeof(int)));
         DARTK_HIP(hipMalloc((void **)&w.sysScratch, (size_t)8 * kMaxSys * sizeof(float)));
         w.rayBuf = nullptr; w.rayFloats = 0;
@@ -45,6 +46,7 @@ int get_workspace(Workspace **out) {
         DARTK_HIP(hipEventCreateWithFlags(&w.evJoin, hipEventDisableTiming));
         DARTK_HIP(hipStreamCreateWithFlags(&w.auxStream2, hipStreamNonBlocking));
         DARTK_HIP(hipEventCreateWithFlags(&w.evObs, hipEventDisableTiming));
+        DARTK_HIP(hipEventCreateWithFlags(&w.evJoin2, hipEventDisableTiming));
         g_ws_ready[dev] = true;
     }
     *out = &g_ws[dev];
@@ -70,8 +72,8 @@ int ensure_partials(Workspace *w, size_t floats) {
     if (floats <= w->partialFloats) return DARTK_OK;
     DARTK_HIP(hipDeviceSynchronize());
     DARTK_HIP(hipFree(w->partials));
-    w->partialFloats = floats;
-    DARTK_HIP(hipMalloc((void **)&w->partials, floats * sizeof(float)));
+    w->partialFloats = floats;          // per lane
+    DARTK_HIP(hipMalloc((void **)&w->partials, kPartialLanes * floats * sizeof(float)));
     return DARTK_OK;
 }
 

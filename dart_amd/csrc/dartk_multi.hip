@@ -5,6 +5,8 @@
 // applies regularisation + LM scaling, runs the reference's upper-triangular back substitution (SURVEY A-1), updates the
 // reduced poses with their limits, projects them to full joint vectors and runs forward kinematics. No host round trip.
 #include "dartk_internal.h"
+
+#include <cstdlib>
 #include "dartk_reduce.h"
 #include "dartk_kernels.h"
 #include "dartk_fk.h"
@@ -308,7 +310,19 @@ int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *
     if (ldsSolve > 64 * 1024)
         DARTK_HIP(hipFuncSetAttribute((const void *)multi_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
     const int nPix = width * height;
+    // Three chains per iteration meet only in the solve: ray-cast -> cull -> mod->obs (the longest, on the caller's stream),
+    // association -> obs->mod, and the intersection terms; the two shorter ones run on the side streams, each term wrapper
+    // writing its partial systems into its chain's lane of the slab buffer.
+    struct LaneGuard { Workspace *w; ~LaneGuard() { w->partialLane = 0; } } laneGuard{ws};
+    const bool par = o->numIterations > 0 && getenv("DARTK_MULTI_ONE_STREAM") == nullptr;
+    hipStream_t stA = par ? ws->auxStream : st, stC = par ? ws->auxStream2 : st;
     for (int it = 0; it < o->numIterations; ++it) {
+        if (par) {      // the poses of this iteration are final on `st`
+            DARTK_HIP(hipEventRecord(ws->evFork, st));
+            DARTK_HIP(hipStreamWaitEvent(stA, ws->evFork, 0));
+            DARTK_HIP(hipStreamWaitEvent(stC, ws->evFork, 0));
+        }
+        ws->partialLane = 0;
         if (useB) {     // raytracePrediction of every model into one map + cullUnobservable (:610-618)
             for (int m = 0; m < n; ++m) {
                 rc = gn_launch_raycast(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2), o->predWidth,
@@ -318,40 +332,53 @@ int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *
             rc = gn_launch_cull(d_prediction, o->predWidth, o->predHeight, d_vert, width, height, st);
             if (rc) return rc;
             DARTK_HIP(hipMemsetAsync(d_countB, 0, n * sizeof(int), st));
-        }
-        if (useA) {
-            ProfScope ps(DARTK_PROF_OTHER, st);
-            rc = gn_assoc_multi_launch(d_vert, nPix, n, d_assocArgs, d_countA, st);
-            if (rc) return rc;
-        }
-        for (int m = 0; m < n; ++m) {
-            const MultiSolveModel &s = h.m[m];
-            const int fullDims = 6 + mods[m]->v.nJoints;
-            if (useA) {
-                ProfScope ps(DARTK_PROF_FUSED_OBS2MOD, st);
-                rc = gn_launch_ne_obs2mod_dev(s.redType, fullDims, s.dims, d_vert, mods[m], o->huberDelta, mm[m].d_pts, d_countA + m, nPix,
-                                              mm[m].d_A, mm[m].d_map, sysA[m], st);
-                if (rc) return rc;
-            }
-            if (useB) {     // reduced wrappers use the model's current T_mc, the full one T_obsSdf_c (modToObs.cu:851-988 vs :713-780)
+            for (int m = 0; m < n; ++m) {   // reduced wrappers use the model's current T_mc, the full one T_obsSdf_c (modToObs.cu:851-988 vs :713-780)
+                const MultiSolveModel &s = h.m[m];
                 ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
-                rc = gn_ne_mod2obs_any(s.redType, fullDims, s.dims, d_prediction, o->predWidth, o->predHeight, mods[m],
+                rc = gn_ne_mod2obs_any(s.redType, 6 + mods[m]->v.nJoints, s.dims, d_prediction, o->predWidth, o->predHeight, mods[m],
                                        s.redType == 0 ? T_obs[m] : mods[m]->v.T_mc, mm[m].d_A, mm[m].d_map, sysB[m], d_countB + m, st);
                 if (rc) return rc;
             }
+        }
+        ws->partialLane = 1;
+        if (useA) {
+            {
+                ProfScope ps(DARTK_PROF_OTHER, stA);
+                rc = gn_assoc_multi_launch(d_vert, nPix, n, d_assocArgs, d_countA, stA);
+                if (rc) return rc;
+            }
+            for (int m = 0; m < n; ++m) {
+                const MultiSolveModel &s = h.m[m];
+                ProfScope ps(DARTK_PROF_FUSED_OBS2MOD, stA);
+                rc = gn_launch_ne_obs2mod_dev(s.redType, 6 + mods[m]->v.nJoints, s.dims, d_vert, mods[m], o->huberDelta, mm[m].d_pts,
+                                              d_countA + m, nPix, mm[m].d_A, mm[m].d_map, sysA[m], stA);
+                if (rc) return rc;
+            }
+        }
+        ws->partialLane = 2;
+        for (int m = 0; m < n; ++m) {
+            const MultiSolveModel &s = h.m[m];
+            const int fullDims = 6 + mods[m]->v.nJoints;
             if (s.sysC) {
-                ProfScope ps(DARTK_PROF_NE_SELF, st);
+                ProfScope ps(DARTK_PROF_NE_SELF, stC);
                 rc = gn_ne_self_any(s.redType, mm[m].d_cloud, mm[m].nCloud, fullDims, s.dims, mods[m], mm[m].d_A, mm[m].d_map,
-                                    mm[m].d_potential, sysC[m], st);
+                                    mm[m].d_potential, sysC[m], stC);
                 if (rc) return rc;
             }
             for (int d = 0; d < n; ++d) {
                 if (!s.sysI[d]) continue;
-                ProfScope ps(DARTK_PROF_NE_SELF, st);
+                ProfScope ps(DARTK_PROF_NE_SELF, stC);
                 rc = gn_ne_inter_any(s.redType, mm[m].d_cloud, mm[m].nCloud, fullDims, s.dims, mods[m], mods[d], mm[m].d_A, mm[m].d_map,
-                                     T_pair[m], sysI[m][d], st);
+                                     T_pair[m], sysI[m][d], stC);
                 if (rc) return rc;
             }
+        }
+        ws->partialLane = 0;
+        if (par) {
+            DARTK_HIP(hipEventRecord(ws->evJoin, stA));
+            DARTK_HIP(hipEventRecord(ws->evJoin2, stC));
+            DARTK_HIP(hipStreamWaitEvent(st, ws->evJoin, 0));
+            DARTK_HIP(hipStreamWaitEvent(st, ws->evJoin2, 0));
         }
         {
             ProfScope ps(DARTK_PROF_SOLVE, st);

@@ -240,14 +240,14 @@ static int launch_ne_obs2mod(int fullDims, int redDims, const float *d_vert, Mod
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
         hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, nElements, m,         \
-                           huberDelta, redDims, d_A, d_map, ws->partials, (const int *)nullptr);                \
+                           huberDelta, redDims, d_A, d_map, lane_partials(ws), (const int *)nullptr);                \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_NE(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_NE(6);
     else DARTK_LAUNCH_NE(20);
 #undef DARTK_LAUNCH_NE
     DARTK_HIP(hipGetLastError());
-    return launch_reduce_slabs(ws->partials, nBlocks, S, d_result, 1, st);
+    return launch_reduce_slabs(lane_partials(ws), nBlocks, S, d_result, 1, st);
 }
 
 // the same normal equations with the list length read on the device (*d_count, at most maxElements): a fixed grid walks
@@ -276,14 +276,14 @@ static int launch_ne_obs2mod_dev(int fullDims, int redDims, const float *d_vert,
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
         hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, maxElements, m,       \
-                           huberDelta, redDims, d_A, d_map, ws->partials, d_count);                             \
+                           huberDelta, redDims, d_A, d_map, lane_partials(ws), d_count);                             \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_NE(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_NE(6);
     else DARTK_LAUNCH_NE(20);
 #undef DARTK_LAUNCH_NE
     DARTK_HIP(hipGetLastError());
-    return launch_reduce_slabs_gated(ws->partials, nBlocks, S, d_result, d_count, 10, st);
+    return launch_reduce_slabs_gated(lane_partials(ws), nBlocks, S, d_result, d_count, 10, st);
 }
 
 int gn_launch_ne_obs2mod_dev(int red, int fullDims, int redDims, const float *d_vert, Model *mod, float huberDelta,
