@@ -188,6 +188,14 @@ class TrackerNoObs:
         self.priors.append(prior)
         self._handle = None
 
+    def clearPriors(self):
+        """TrackerNoObs::clearPriors (tracker_no_obs.h): drops the contact and the point priors."""
+        if self.priors:
+            self.priors = []
+            self._handle = None
+        self.point_priors = []
+        self._points_sig = None
+
     def setPose(self, model_num, T_mc, joints):
         self.T_mc[model_num] = np.ascontiguousarray(T_mc, dtype=F).reshape(12)
         self.joints[model_num] = np.ascontiguousarray(joints, dtype=F).reshape(-1)
