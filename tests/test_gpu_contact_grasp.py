@@ -155,3 +155,36 @@ def test_edge_cases(gpu):
     tr3 = configs.make_grasp_tracker(sc2)
     with pytest.raises(_abi.DartkError):
         tr3.getError(T1, j1)
+
+
+def test_full_size_batch_properties(gpu):
+    """BASELINE config 4 at its full size (4096 candidates x 2501 priors), through properties that need no oracle run of
+    the whole batch: (i) a sample of candidates against the oracle, (ii) reversing the batch reverses the result bit for
+    bit, (iii) duplicated candidates give duplicated results, (iv) getError at the refined poses is the returned energy."""
+    n = 4096
+    sc = scene(n)
+    tr = configs.make_grasp_tracker(sc, max_batch=n)
+    T, j = configs.grasp_batch_arrays(sc)
+    T, j = T.copy(), j.copy()
+    T[n - 7], j[n - 7] = T[11], j[11]           # duplicates far apart in the batch (different workgroups, different XCDs)
+    T[2048], j[2048] = T[11], j[11]
+    iters = 3
+    tr.getOptions().numIterations = iters
+    gT, gj, ge, _, _ = tr.optimizePosesBatch(T, j)
+    assert np.isfinite(gT).all() and np.isfinite(gj).all() and np.isfinite(ge).all()
+    for c in (n - 7, 2048):
+        assert np.array_equal(gT[c], gT[11]) and np.array_equal(gj[c], gj[11]) and ge[c] == ge[11]
+    rT, rj, re_, _, _ = tr.optimizePosesBatch(T[::-1].copy(), j[::-1].copy())
+    assert np.array_equal(rT[::-1], gT) and np.array_equal(rj[::-1], gj) and np.array_equal(re_[::-1], ge)
+    for c in (0, 11, 1500, 3333, n - 1):
+        oT, oj, oe, _, _ = oracle_run(sc, tr, T[c, 0], j[c], iters)
+        dt, dr = pose_diff(gT[c, 0], oT[0])
+        dj = float(np.abs(gj[c] - oj[0]).max())
+        print("candidate %4d of %d: |dt|=%.2e |dr|=%.2e max|dq|=%.2e energy gpu %.6f oracle %.6f" % (c, n, dt, dr, dj, ge[c], oe))
+        assert dt < 1e-3 and dr < 1e-3 and dj < 1e-3
+        assert abs(ge[c] - oe) < 1e-3 * max(1.0, abs(oe))
+    e2 = tr.getError(gT, gj)
+    assert np.allclose(e2, ge, rtol=1e-6, atol=1e-7)
+    # the refinement lowers the mean energy of the batch
+    e0 = tr.getError(T, j)
+    assert float(np.mean(ge)) < float(np.mean(e0))
