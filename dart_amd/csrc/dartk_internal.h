@@ -36,6 +36,8 @@ struct SdfDev {               // 64 bytes
     // it is skipped: identical results, far fewer gathers than the reference's padded grids imply (padding 10 cm).
     float keepLo[4][3], keepHi[4][3];       // keep iff keepLo <= g < keepHi on every axis
 };
+static constexpr int kSdfWords = (int)(sizeof(SdfDev) / 4);
+static_assert(sizeof(SdfDev) % 4 == 0, "SdfDev is copied word by word");
 static constexpr float kNearThr[3] = {0.02f, 0.03f, 0.05f};
 // box to use for a distance threshold (metres): the tightest one that still covers it; -1 = no pruning
 __host__ __device__ inline int keep_slot(float thr) {

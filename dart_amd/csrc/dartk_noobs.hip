@@ -138,6 +138,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     __shared__ double sErr[NE_BLOCK / 64];
     __shared__ int sOff[DARTK_MAX_MODELS + 1];
     __shared__ int sSphOff[DARTK_MAX_MODELS + 1];
+    __shared__ int sSdfOff[DARTK_MAX_MODELS + 1];      // per model: SdfDev headers, then the SDF -> frame table
     const int c = blockIdx.y;
     const NoObsTerm &T = P->term[termIdx];
     const int nModels = P->nModels;
@@ -149,8 +150,20 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         sOff[nModels] = o;
         for (int mi = 0; mi < nModels; ++mi) { sSphOff[mi] = o; o += kSphereStride * P->model[mi].nSdfs; }
         sSphOff[nModels] = o;
+        for (int mi = 0; mi < nModels; ++mi) { sSdfOff[mi] = o; o += (kSdfWords + 1) * P->model[mi].nSdfs; }
+        sSdfOff[nModels] = o;
     }
     __syncthreads();
+    // SDF headers and SDF -> frame tables: read per (point, SDF) pair in the test loops, from LDS instead of through
+    // generic pointers into the arena (vector loads of wave-uniform values)
+    for (int mi = 0; mi < nModels; ++mi) {
+        const ModelView &mv = P->model[mi];
+        int *p = reinterpret_cast<int *>(lds + sSdfOff[mi]);
+        const int *srcW = reinterpret_cast<const int *>(mv.sdfs);
+        const int nw = kSdfWords * mv.nSdfs;
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) p[i] = srcW[i];
+        for (int i = threadIdx.x; i < mv.nSdfs; i += blockDim.x) p[nw + i] = mv.sdfFrame[i];
+    }
     for (int mi = 0; mi < nModels; ++mi) {
         float *p = lds + sOff[mi];
         const ModelView mv = rebase(P->model[mi], poseC + P->poseOff[mi]);
@@ -159,6 +172,8 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     }
 #define sTf(mi) (lds + sOff[mi])
 #define sSph(mi) (lds + sSphOff[mi])
+#define sSdf(mi) (reinterpret_cast<const SdfDev *>(lds + sSdfOff[mi]))
+#define sFrm(mi, nSdfs_) (reinterpret_cast<const int *>(lds + sSdfOff[mi]) + kSdfWords * (nSdfs_))
     __syncthreads();
     // bounding spheres of every SDF's keep boxes in its model's frame (see make_spheres)
     for (int mi = 0; mi < nModels; ++mi) {
@@ -168,11 +183,13 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     }
     const int d = T.dims;
     const int ld = noobs_row_len(TYPE, d);
-    float *rows = lds + sSphOff[nModels];
+    float *rows = lds + sSdfOff[nModels];
     int *waveCnt = reinterpret_cast<int *>(rows + NOOBS_ROWS * ld);
     int *sPot = waveCnt + 8;            // the self term's potential-intersection matrix (when it fits)
-    const ModelView src = rebase(P->model[T.src], poseC + P->poseOff[T.src]);
-    const ModelView dst = rebase(P->model[T.dst], poseC + P->poseOff[T.dst]);
+    ModelView src = rebase(P->model[T.src], poseC + P->poseOff[T.src]);
+    ModelView dst = rebase(P->model[T.dst], poseC + P->poseOff[T.dst]);
+    src.sdfs = sSdf(T.src); src.sdfFrame = sFrm(T.src, src.nSdfs);
+    dst.sdfs = sSdf(T.dst); dst.sdfFrame = sFrm(T.dst, dst.nSdfs);
     const int *potPtr = T.pot;
     if (TYPE == TERM_SELF) {
         const int nn = src.nSdfs * src.nSdfs;
@@ -339,7 +356,9 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                     const ModelView md = rebase(P->model[pDst], poseC + P->poseOff[pDst]);
                     const float *sfm = sTf(pSrc), *smf = sTf(pSrc) + 12 * ms.nFrames;
                     const float *dfm = sTf(pDst), *dmf = sTf(pDst) + 12 * md.nFrames;
-                    srcFrame = ms.sdfFrame[pr.srcSdf];
+                    const SdfDev *mdSdfs = sSdf(pDst);
+                    const int *mdFrame = sFrm(pDst, md.nSdfs);
+                    srcFrame = sFrm(pSrc, ms.nSdfs)[pr.srcSdf];
                     pm = se3_apply_w(smf + 12 * srcFrame, pr.contactPoint[0], pr.contactPoint[1], pr.contactPoint[2], 1.0f);
                     const f3 cc = se3_apply_w(ms.T_cm, pm.x, pm.y, pm.z, 1.0f);
                     pdm = se3_apply_w(md.T_mc, cc.x, cc.y, cc.z, 1.0f);
@@ -354,16 +373,16 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                     const float *sph = sSph(pDst) + 4 * (slot < 0 ? 4 : slot);
                     for (int ds = 0; ds < md.nSdfs; ++ds) {
                         if (sphere_reject(sph + kSphereStride * ds, pdm)) continue;
-                        const SdfDev &s = md.sdfs[ds];
-                        const f3 df = se3_apply_w(dfm + 12 * md.sdfFrame[ds], pdm.x, pdm.y, pdm.z, 1.0f);
+                        const SdfDev &s = mdSdfs[ds];
+                        const f3 df = se3_apply_w(dfm + 12 * mdFrame[ds], pdm.x, pdm.y, pdm.z, 1.0f);
                         const f3 g = grid_coords(s, df);
                         if (!in_bounds_interp(s, g) || !in_keep_box(s, slot, g)) continue;
                         const float v = grid_value(md.grids + s.dataOff, s.dimx, s.dimy, g);
                         if (v < minV) { minV = v; dstSdf = ds; }
                     }
                     if (dstSdf >= 0) {
-                        dstFrame = md.sdfFrame[dstSdf];
-                        const SdfDev &s = md.sdfs[dstSdf];
+                        dstFrame = mdFrame[dstSdf];
+                        const SdfDev &s = mdSdfs[dstSdf];
                         const f3 cdf = se3_apply_w(dfm + 12 * dstFrame, pdm.x, pdm.y, pdm.z, 1.0f);
                         const f3 cg = grid_coords(s, cdf);
                         if (in_bounds_grad_interp(s, cg)) {
@@ -713,7 +732,7 @@ int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *co
     int nTerms = 0, slabOff = 0, SMax = 0;
     int ldsModels = 0, potInts = 0;
     for (int m = 0; m < nModels; ++m) {
-        ldsModels += 24 * P.model[m].nFrames + kSphereStride * P.model[m].nSdfs;
+        ldsModels += 24 * P.model[m].nFrames + kSphereStride * P.model[m].nSdfs + (kSdfWords + 1) * P.model[m].nSdfs;
         if (P.model[m].nSdfs * P.model[m].nSdfs > potInts) potInts = P.model[m].nSdfs * P.model[m].nSdfs;
     }
     t->potLdsInts = potInts <= 4096 ? potInts : 0;
