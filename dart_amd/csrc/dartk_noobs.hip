@@ -150,7 +150,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         sOff[nModels] = o;
         for (int mi = 0; mi < nModels; ++mi) { sSphOff[mi] = o; o += kSphereStride * P->model[mi].nSdfs; }
         sSphOff[nModels] = o;
-        for (int mi = 0; mi < nModels; ++mi) { sSdfOff[mi] = o; o += (kSdfWords + 1) * P->model[mi].nSdfs; }
+        for (int mi = 0; mi < nModels; ++mi) { sSdfOff[mi] = o; o += (kSdfWords + 1) * P->model[mi].nSdfs + 24; }
         sSdfOff[nModels] = o;
     }
     __syncthreads();
@@ -163,6 +163,9 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         const int nw = kSdfWords * mv.nSdfs;
         for (int i = threadIdx.x; i < nw; i += blockDim.x) p[i] = srcW[i];
         for (int i = threadIdx.x; i < mv.nSdfs; i += blockDim.x) p[nw + i] = mv.sdfFrame[i];
+        const float *pose = poseC + P->poseOff[mi];         // the candidate's [T_mc | T_cm] of this model
+        float *pp = lds + sSdfOff[mi] + (kSdfWords + 1) * mv.nSdfs;
+        for (int i = threadIdx.x; i < 24; i += blockDim.x) pp[i] = pose[i];
     }
     for (int mi = 0; mi < nModels; ++mi) {
         float *p = lds + sOff[mi];
@@ -174,6 +177,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
 #define sSph(mi) (lds + sSphOff[mi])
 #define sSdf(mi) (reinterpret_cast<const SdfDev *>(lds + sSdfOff[mi]))
 #define sFrm(mi, nSdfs_) (reinterpret_cast<const int *>(lds + sSdfOff[mi]) + kSdfWords * (nSdfs_))
+#define sPoseT(mi, nSdfs_) (lds + sSdfOff[mi] + (kSdfWords + 1) * (nSdfs_))      /* T_mc at +0, T_cm at +12 */
     __syncthreads();
     // bounding spheres of every SDF's keep boxes in its model's frame (see make_spheres)
     for (int mi = 0; mi < nModels; ++mi) {
@@ -360,8 +364,8 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                     const int *mdFrame = sFrm(pDst, md.nSdfs);
                     srcFrame = sFrm(pSrc, ms.nSdfs)[pr.srcSdf];
                     pm = se3_apply_w(smf + 12 * srcFrame, pr.contactPoint[0], pr.contactPoint[1], pr.contactPoint[2], 1.0f);
-                    const f3 cc = se3_apply_w(ms.T_cm, pm.x, pm.y, pm.z, 1.0f);
-                    pdm = se3_apply_w(md.T_mc, cc.x, cc.y, cc.z, 1.0f);
+                    const f3 cc = se3_apply_w(sPoseT(pSrc, ms.nSdfs) + 12, pm.x, pm.y, pm.z, 1.0f);
+                    pdm = se3_apply_w(sPoseT(pDst, md.nSdfs), cc.x, cc.y, cc.z, 1.0f);
                     // nearest destination SDF by raw voxel-unit value among isInBoundsInterp grids (:41-54; the
                     // reference loop bound `<= getNumSdfs()` reads one element past the end -- restated with `<`)
                     // With one resolution for all of the model's SDFs the raw-value arg-min and the metric gate order alike,
@@ -392,8 +396,8 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                                 else {
                                     const f3 g_df = grid_gradient(md.grids + s.dataOff, s.dimx, s.dimy, cg);
                                     gdm = se3_rotate(dmf + 12 * dstFrame, g_df);
-                                    const f3 g_c = se3_rotate(md.T_cm, gdm);
-                                    gs = se3_rotate(ms.T_mc, g_c);
+                                    const f3 g_c = se3_rotate(sPoseT(pDst, md.nSdfs) + 12, gdm);
+                                    gs = se3_rotate(sPoseT(pSrc, ms.nSdfs), g_c);
                                     bool keep = true;
                                     if (pr.invert && err > 0) {            // repulsive cylinder test, :84-89
                                         const f3 g_sf = se3_rotate(sfm + 12 * srcFrame, gs);
@@ -732,7 +736,7 @@ int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *co
     int nTerms = 0, slabOff = 0, SMax = 0;
     int ldsModels = 0, potInts = 0;
     for (int m = 0; m < nModels; ++m) {
-        ldsModels += 24 * P.model[m].nFrames + kSphereStride * P.model[m].nSdfs + (kSdfWords + 1) * P.model[m].nSdfs;
+        ldsModels += 24 * P.model[m].nFrames + kSphereStride * P.model[m].nSdfs + (kSdfWords + 1) * P.model[m].nSdfs + 24;
         if (P.model[m].nSdfs * P.model[m].nSdfs > potInts) potInts = P.model[m].nSdfs * P.model[m].nSdfs;
     }
     t->potLdsInts = potInts <= 4096 ? potInts : 0;
