@@ -156,6 +156,33 @@ __device__ __forceinline__ Collision first_collision(const ModelView &dst, const
     Collision c;
     c.hit = false; c.dstGrid = -1; c.residual = 0.0f; c.vg.x = c.vg.y = c.vg.z = 0.0f;
     const int n = dst.nSdfs;
+    if (sph && n <= 64) {
+        // Two passes instead of a chain of divergent early-outs per SDF: first a branch-free candidate mask per lane
+        // (potential matrix and bounding sphere), whose union over the wave is kept in a scalar; then only the SDFs some
+        // lane still wants are visited, in SDF order, so every lane still meets its candidates in the reference's order
+        // and stops at its first penetrated one.
+        unsigned long long cand = 0ull, any = 0ull;
+        for (int g = 0; g < n; ++g) {
+            const bool ok = !(pot && !pot[g + srcGrid * n]) && !sphere_reject(sph + kSphereStride * g, v_dm);
+            cand |= (unsigned long long)ok << g;
+            if (__builtin_amdgcn_ballot_w64(ok) != 0ull) any |= 1ull << g;
+        }
+        while (any != 0ull) {
+            const int g = (int)__builtin_ctzll(any);
+            any &= any - 1ull;
+            if ((cand >> g) & 1ull) {
+                const SdfDev &s = dst.sdfs[g];
+                const int f = dst.sdfFrame[g];
+                const f3 vd = se3_apply_w(T_fm_dst + 12 * f, v_dm.x, v_dm.y, v_dm.z, 1.0f);
+                const f3 vg = grid_coords(s, vd);
+                if (in_bounds_grad_interp(s, vg) && in_keep_box(s, 0, vg)) {       // r < 0 needs a negative corner
+                    const float r = grid_value(dst.grids + s.dataOff, s.dimx, s.dimy, vg) * s.res;
+                    if (r < 0) { c.hit = true; c.dstGrid = g; c.residual = r; c.vg = vg; cand = 0ull; }
+                }
+            }
+        }
+        return c;
+    }
     for (int g = 0; g < n; ++g) {
         if (pot && !pot[g + srcGrid * n]) continue;
         if (sph && sphere_reject(sph + kSphereStride * g, v_dm)) continue;
