@@ -22,6 +22,7 @@ struct RayGeom { f3 of, dn; };
 #ifdef DARTK_STAMPS
 __device__ int g_rayMaxSteps;                    // diagnostic build only: longest march, total steps, marched rays
 __device__ unsigned long long g_raySteps, g_rayMarched;
+__device__ unsigned long long g_rayPhase[6];     // longest wave: passes, cycles of coords / load wait / interpolation+step; all waves: passes, cycles
 #endif
 
 // ray of pixel (x,y) expressed in the frame of an SDF whose camera->frame transform is T_fc (raycast.cu:147-161)
@@ -129,6 +130,58 @@ raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int 
         int steps = 0;
 #endif
         const float minStep = res / 10;
+#ifdef DARTK_STAMPS
+        // diagnostic build: the same loop with cycle stamps between its three phases (coordinates, load wait, interpolation +
+        // step); the stamps cost ~100 cycles each, so only the split is meaningful
+        unsigned long long cA = 0, cB = 0, cC = 0, passes = 0;
+        const unsigned long long w0 = __builtin_readcyclecounter();
+        while (t0 < t1 && t0 < 10000.0f) {
+            const unsigned long long s0 = __builtin_readcyclecounter();
+            f3 xf, xg;
+            xf.x = dn.x * t0 + of.x; xf.y = dn.y * t0 + of.y; xf.z = dn.z * t0 + of.z;
+            const float dx = xf.x - ox, dy = xf.y - oy, dz = xf.z - oz;
+            if (exactDiv) { xg.x = div_exact(dx, res, rcp); xg.y = div_exact(dy, res, rcp); xg.z = div_exact(dz, res, rcp); }
+            else { xg.x = dx / res; xg.y = dy / res; xg.z = dz / res; }
+            xg.x = fmaxf(1.0f, fminf(xg.x, hix)); xg.y = fmaxf(1.0f, fminf(xg.y, hiy)); xg.z = fmaxf(1.0f, fminf(xg.z, hiz));
+            const float tx = xg.x - 0.5f, ty = xg.y - 0.5f, tz = xg.z - 0.5f;
+            const int x0 = (int)tx, y0 = (int)ty, z0 = (int)tz;
+            const float fx = tx - (float)x0, fy = ty - (float)y0, fz = tz - (float)z0;
+            const float *p = data + (x0 + dimx * (y0 + dimy * z0));
+            asm volatile("" :: "v"(fx), "v"(fy), "v"(fz), "v"(p));
+            const unsigned long long s1 = __builtin_readcyclecounter();
+            const f2u q00 = *reinterpret_cast<const f2u *>(p), q10 = *reinterpret_cast<const f2u *>(p + dimx);
+            const f2u q01 = *reinterpret_cast<const f2u *>(p + dimx * dimy), q11 = *reinterpret_cast<const f2u *>(p + dimx * dimy + dimx);
+            asm volatile("s_waitcnt vmcnt(0)" :: "v"(q00.a), "v"(q10.a), "v"(q01.a), "v"(q11.a) : "memory");
+            const unsigned long long s2 = __builtin_readcyclecounter();
+            const float dx00 = lerpf(q00.a, q00.b, fx), dx01 = lerpf(q01.a, q01.b, fx), dx10 = lerpf(q10.a, q10.b, fx), dx11 = lerpf(q11.a, q11.b, fx);
+            const float sdfVal = lerpf(lerpf(dx00, dx10, fy), lerpf(dx01, dx11, fy), fz) * res;
+            bool crossedNow = false;
+            if (sdfValPrev > levelSet && sdfVal <= levelSet) {
+                det = t0;
+                hit = (t0 - tPrev) * (levelSet - sdfValPrev) / (sdfVal - sdfValPrev) + tPrev;
+                crossedNow = true;
+            } else {
+                sdfValPrev = sdfVal;
+                tPrev = t0;
+                t0 += fmaxf(minStep, fabsf(sdfVal));
+                ++steps;
+            }
+            asm volatile("" :: "v"(t0), "v"(det));
+            const unsigned long long s3 = __builtin_readcyclecounter();
+            cA += s1 - s0; cB += s2 - s1; cC += s3 - s2; ++passes;
+            if (crossedNow) break;
+        }
+        {
+            const unsigned long long wc = __builtin_readcyclecounter() - w0;
+            const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+            if (lane == (int)__builtin_ctzll(ex)) {
+                atomicAdd(&g_rayPhase[4], passes); atomicAdd(&g_rayPhase[5], wc);
+                if (atomicMax(&g_rayPhase[0], passes) < passes) {        // (racy among equals: diagnostic only)
+                    g_rayPhase[1] = cA; g_rayPhase[2] = cB; g_rayPhase[3] = cC;
+                }
+            }
+        }
+#else
         while (t0 < t1 && t0 < 10000.0f) {      // 10000 = the reference's initial closestT
             const float sdfVal = eval(t0);
             if (sdfValPrev > levelSet && sdfVal <= levelSet) {
@@ -143,6 +196,7 @@ raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int 
             ++steps;
 #endif
         }
+#endif
 #ifdef DARTK_STAMPS
         atomicMax(&g_rayMaxSteps, steps);
         atomicAdd(&g_raySteps, (unsigned long long)steps);
@@ -650,6 +704,10 @@ int dartk_debug_ray_steps(long long *out3) {
     DARTK_HIP(hipMemcpyFromSymbol(&st, HIP_SYMBOL(g_raySteps), sizeof(st)));
     DARTK_HIP(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_rayMarched), sizeof(n)));
     out3[0] = mx; out3[1] = (long long)st; out3[2] = (long long)n;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, zero6[6] = {0, 0, 0, 0, 0, 0};
+    DARTK_HIP(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_rayPhase), sizeof(ph)));
+    for (int i = 0; i < 6; ++i) out3[3 + i] = (long long)ph[i];      // the caller passes 9 slots
+    DARTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rayPhase), zero6, sizeof(zero6)));
     const int z = 0; const unsigned long long zz = 0;
     DARTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rayMaxSteps), &z, sizeof(z)));
     DARTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_raySteps), &zz, sizeof(zz)));

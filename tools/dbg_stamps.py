@@ -18,7 +18,7 @@ print("stamps (us) assemble / ldlt / update+fk per iteration:")
 print(opt.iter_info.cpu().numpy()[:, 5:8] / 100.0)
 import ctypes
 from dart_amd import _abi
-buf = (ctypes.c_longlong * 3)()
+buf = (ctypes.c_longlong * 9)()
 fn = getattr(_abi.lib(), "dartk_debug_ray_steps", None)
 if fn is not None:
     fn(buf)
@@ -26,4 +26,7 @@ if fn is not None:
     opt.optimizePose(dm, vert, norm, sc.opts)
     fn(buf)
     n_it = sc.opts.numIterations
+    if buf[3]:
+        print("longest wave (last launch group): %d passes; cycles per pass: coordinates %.0f, load wait %.0f, interpolation + step %.0f; "
+              "all waves: %.0f cycles per pass" % (buf[3], buf[4] / buf[3], buf[5] / buf[3], buf[6] / buf[3], buf[8] / max(buf[7], 1)))
     print("ray-cast per iteration: longest march %d steps, %.0f marched rays, %.1f steps/ray" % (buf[0], buf[2] / n_it, buf[1] / max(buf[2], 1)))
