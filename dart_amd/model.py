@@ -455,15 +455,21 @@ class HostModel:
                            "orientation": [float(v) for v in self.joint_orientation[j]],
                            "axis": [float(v) for v in self.joint_axis[j]],
                            "limits": [float(v) for v in self.joint_limits[j]], "dh": [float(v) for v in self.dh[j]]})
-        geoms = [{"frame": g["frame"], "type": g["type"], "scale": [float(v) for v in g["scale"]],
-                  "trans": g["trans"], "rot": g["rot"]} for g in self._geom_specs]
+        geoms = []
+        for g in self._geom_specs:
+            spec = {"frame": g["frame"], "type": g["type"], "scale": [float(v) for v in g["scale"]], "trans": g["trans"], "rot": g["rot"]}
+            if g.get("meshFile"):
+                spec["meshFile"] = g["meshFile"]       # from_json(spec, mesh_dir=...) reads it again
+            geoms.append(spec)
         return {"name": self.name, "version": self.version, "frames": frames, "geoms": geoms}
 
     _geom_specs = ()
 
     @classmethod
-    def from_json(cls, spec):
+    def from_json(cls, spec, mesh_dir=None):
         if isinstance(spec, str):
+            if mesh_dir is None:
+                mesh_dir = os.path.dirname(os.path.abspath(spec))
             with open(spec) as fh:
                 spec = json.load(fh)
         m = cls(version=spec.get("version", 1), name=spec.get("name", "model"))
@@ -472,7 +478,13 @@ class HostModel:
                         fr["limits"][1], fr.get("name", ""), fr.get("dh", (0, 0, 0, 0)))
         m._geom_specs = list(spec.get("geoms", []))
         for g in m._geom_specs:
-            m.add_geometry(g["frame"], g["type"], g["scale"], g["trans"], g["rot"])
+            mesh = None
+            if g["type"] == GEOM_MESH:
+                if not g.get("meshFile") or mesh_dir is None:
+                    raise ValueError("mesh geometry in a model description needs meshFile and a mesh directory")
+                from .mesh import read_mesh
+                mesh = read_mesh(os.path.join(mesh_dir, g["meshFile"]))
+            m.add_geometry(g["frame"], g["type"], g["scale"], g["trans"], g["rot"], mesh=mesh)
         return m
 
 

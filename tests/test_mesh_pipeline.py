@@ -120,3 +120,29 @@ def test_sdf_cache_format(tmp_path):
         fh.write(b"x")
     with pytest.raises(ValueError):
         M.read_sdf_cache(p)
+
+
+def test_model_description_keeps_mesh_geometry(tmp_path):
+    """A model read from XML with a mesh geom survives the JSON round trip (the mesh file is named, not embedded)."""
+    import json
+    from dart_amd.model import HostModel, read_model_xml, GEOM_MESH
+    v, f = S.icosphere(radius=1.0, subdivisions=1)
+    M.write_obj(str(tmp_path / "ball.obj"), M.Mesh(v, f))
+    with open(str(tmp_path / "m.xml"), "w") as fh:
+        fh.write('<?xml version="1.0" ?>\n<model version="1">\n  <geom type="mesh" sx="0.03" sy="0.03" sz="0.03" tx="0" ty="0" tz="0" '
+                 'rx="0" ry="0" rz="0" red="0" green="0" blue="0" meshFile="ball.obj"/>\n</model>\n')
+    m = read_model_xml(str(tmp_path / "m.xml"), load_meshes=True)
+    assert m.geoms[0]["type"] == GEOM_MESH and m.geoms[0]["mesh"].n_faces == len(f)
+    lo, hi = m._frame_extent(m.frame_geoms(0))
+    assert np.allclose(lo, -0.03, atol=1e-6) and np.allclose(hi, 0.03, atol=1e-6)
+    spec = m.to_json()
+    assert spec["geoms"][0]["meshFile"] == "ball.obj"
+    with open(str(tmp_path / "m.json"), "w") as fh:
+        json.dump(spec, fh)
+    m2 = HostModel.from_json(str(tmp_path / "m.json"))
+    assert m2.geoms[0]["mesh"].n_faces == len(f) and np.array_equal(m2.geoms[0]["mesh"].vertices, m.geoms[0]["mesh"].vertices)
+    spec["geoms"][0].pop("meshFile")
+    with pytest.raises(ValueError):
+        HostModel.from_json(spec)
+    # without load_meshes and without a proxy the mesh geom is dropped, as before
+    assert len(read_model_xml(str(tmp_path / "m.xml")).geoms) == 0
