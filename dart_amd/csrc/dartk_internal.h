@@ -105,7 +105,7 @@ struct Workspace {
     hipStream_t auxStream; // second stream: the mod->obs chain runs beside the obs->mod chain (fork/join by events)
     int partialLane;       // which third of `partials` the next term wrapper uses (device loops run three chains side by side)
     hipStream_t auxStream2; // third stream: the per-call obs-SDF build runs beside the first ray-cast
-    hipEvent_t evFork, evJoin, evObs, evJoin2;
+    hipEvent_t evFork, evJoin, evObs, evJoin2, evTrace;
 };
 static constexpr int kPartialLanes = 3;
 // the slab buffer of the current lane; partialFloats is the capacity of ONE lane

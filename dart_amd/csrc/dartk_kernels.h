@@ -15,6 +15,11 @@ int ensure_ray_buf(Workspace *w, size_t floats);
 int ensure_valid_idx(Workspace *w, size_t ints);
 
 // kernel-only launchers used by the device-resident Gauss-Newton loops (dartk_gn.hip)
+int gn_raycast_reserve(size_t floats);
+int gn_launch_raycast_trace_at(float flx, float fly, float ppx, float ppy, int width, int height, const ModelView &m, size_t bufOffset,
+                               hipStream_t st);
+int gn_launch_raycast_replay_at(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
+                                float *d_prediction, size_t bufOffset, hipStream_t st);
 int gn_launch_raycast(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                       float *d_prediction, hipStream_t st);
 int gn_launch_cull(float *d_pred, int pw, int ph, const float *d_obs, int ow, int oh, hipStream_t st);

@@ -265,15 +265,15 @@ raycast_replay_kernel(float flx, float fly, float ppx, float ppy, int width, int
 
 // the trace alone (the replay is done by the consumer: ne_mod2obs_kernel<.., REPLAY = true>)
 static int launch_raycast_trace(float flx, float fly, float ppx, float ppy, int width, int height, const ModelView &m, float levelSet,
-                                Workspace *ws, hipStream_t st) {
+                                Workspace *ws, hipStream_t st, size_t bufOffset = 0) {
     const size_t nPix = (size_t)width * height;
-    int rc = ensure_ray_buf(ws, 2 * nPix * (size_t)m.nSdfs);
+    int rc = ensure_ray_buf(ws, bufOffset + 2 * nPix * (size_t)m.nSdfs);     // (callers with an offset have sized the buffer already)
     if (rc) return rc;
     const long long tasks = (long long)((width + 7) / 8) * ((height + 7) / 8) * m.nSdfs;
     DARTK_REQUIRE(tasks < (1ll << 31), "ray-cast of %dx%d against %d SDFs exceeds the launch limits", width, height, m.nSdfs);
     ProfScope ps(DARTK_PROF_RAYCAST, st);
     hipLaunchKernelGGL(raycast_trace_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height, m,
-                       (float2 *)ws->rayBuf, levelSet);
+                       (float2 *)(ws->rayBuf + bufOffset), levelSet);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
@@ -608,6 +608,34 @@ int gn_launch_ne_mod2obs(const float *d_pred, int width, int height, const Model
 int gn_launch_raycast(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                       float *d_prediction, hipStream_t st) {
     return launch_raycast(flx, fly, ppx, ppy, width, height, modelNum, m, d_prediction, 0.0f, st);
+}
+// the two halves apart, with the model's slice of the trace buffer named by the caller: the traces of several models are
+// independent and may run side by side; the replays write one prediction map and keep the model order
+int gn_raycast_reserve(size_t floats) {
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    return ensure_ray_buf(ws, floats);
+}
+int gn_launch_raycast_trace_at(float flx, float fly, float ppx, float ppy, int width, int height, const ModelView &m, size_t bufOffset,
+                               hipStream_t st) {
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    DARTK_REQUIRE(bufOffset + 2 * (size_t)width * height * m.nSdfs <= ws->rayFloats, "trace buffer was not reserved");
+    return launch_raycast_trace(flx, fly, ppx, ppy, width, height, m, 0.0f, ws, st, bufOffset);
+}
+int gn_launch_raycast_replay_at(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
+                                float *d_prediction, size_t bufOffset, hipStream_t st) {
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    const size_t nPix = (size_t)width * height;
+    ProfScope ps2(DARTK_PROF_RAYCAST_REPLAY, st);
+    hipLaunchKernelGGL(raycast_replay_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height,
+                       modelNum, m, (const float2 *)(ws->rayBuf + bufOffset), (float4 *)d_prediction);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
 }
 // ray-cast + mod->obs normal equations of the same prediction: the trace kernel, then ONE kernel that replays each pixel's
 // traces (writing the prediction for the caller) and goes on with the pixel -- one launch less on the critical path

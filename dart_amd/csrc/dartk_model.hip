@@ -47,6 +47,7 @@ int get_workspace(Workspace **out) {
         DARTK_HIP(hipStreamCreateWithFlags(&w.auxStream2, hipStreamNonBlocking));
         DARTK_HIP(hipEventCreateWithFlags(&w.evObs, hipEventDisableTiming));
         DARTK_HIP(hipEventCreateWithFlags(&w.evJoin2, hipEventDisableTiming));
+        DARTK_HIP(hipEventCreateWithFlags(&w.evTrace, hipEventDisableTiming));
         g_ws_ready[dev] = true;
     }
     *out = &g_ws[dev];

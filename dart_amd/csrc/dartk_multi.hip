@@ -314,6 +314,9 @@ int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *
     // association -> obs->mod, and the intersection terms; the two shorter ones run on the side streams, each term wrapper
     // writing its partial systems into its chain's lane of the slab buffer.
     struct LaneGuard { Workspace *w; ~LaneGuard() { w->partialLane = 0; } } laneGuard{ws};
+    size_t traceOff[DARTK_MAX_MODELS], traceFloats = 0;         // every model's slice of the ray-cast trace buffer
+    for (int m = 0; m < n; ++m) { traceOff[m] = traceFloats; traceFloats += 2 * (size_t)o->predWidth * o->predHeight * mods[m]->v.nSdfs; }
+    if (useB) { rc = gn_raycast_reserve(traceFloats); if (rc) return rc; }
     const bool par = o->numIterations > 0 && getenv("DARTK_MULTI_ONE_STREAM") == nullptr;
     hipStream_t stA = par ? ws->auxStream : st, stC = par ? ws->auxStream2 : st;
     for (int it = 0; it < o->numIterations; ++it) {
@@ -324,9 +327,21 @@ int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *
         }
         ws->partialLane = 0;
         if (useB) {     // raytracePrediction of every model into one map + cullUnobservable (:610-618)
+            // the traces of the models are independent: the first runs here, the others on the intersection chain's stream
+            // ahead of its terms; the replays follow in model order on this stream (they share the prediction map)
+            const float ppx = (float)(o->predWidth / 2), ppy = (float)(o->predHeight / 2);
             for (int m = 0; m < n; ++m) {
-                rc = gn_launch_raycast(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2), o->predWidth,
-                                       o->predHeight, m, mods[m]->v, d_prediction, st);
+                rc = gn_launch_raycast_trace_at(o->predFl[0], o->predFl[1], ppx, ppy, o->predWidth, o->predHeight, mods[m]->v, traceOff[m],
+                                                (par && m > 0) ? stC : st);
+                if (rc) return rc;
+            }
+            if (par && n > 1) {
+                DARTK_HIP(hipEventRecord(ws->evTrace, stC));
+                DARTK_HIP(hipStreamWaitEvent(st, ws->evTrace, 0));      // after this stream's own trace, which takes as long
+            }
+            for (int m = 0; m < n; ++m) {
+                rc = gn_launch_raycast_replay_at(o->predFl[0], o->predFl[1], ppx, ppy, o->predWidth, o->predHeight, m, mods[m]->v,
+                                                 d_prediction, traceOff[m], st);
                 if (rc) return rc;
             }
             rc = gn_launch_cull(d_prediction, o->predWidth, o->predHeight, d_vert, width, height, st);
