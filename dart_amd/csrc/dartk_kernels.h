@@ -20,6 +20,9 @@ int gn_launch_raycast_trace_at(float flx, float fly, float ppx, float ppy, int w
                                hipStream_t st);
 int gn_launch_raycast_replay_at(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                                 float *d_prediction, size_t bufOffset, hipStream_t st);
+int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float ppy, int width, int height, int nModels,
+                                        Model *const *mods, const size_t *bufOffsets, float *d_prediction, const float *d_obs, int ow,
+                                        int oh, hipStream_t st);
 int gn_launch_raycast(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                       float *d_prediction, hipStream_t st);
 int gn_launch_cull(float *d_pred, int pw, int ph, const float *d_obs, int ow, int oh, hipStream_t st);

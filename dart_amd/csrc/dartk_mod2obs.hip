@@ -263,6 +263,46 @@ raycast_replay_kernel(float flx, float fly, float ppx, float ppy, int width, int
     if (valid) prediction[index] = pr;
 }
 
+// every model's replay in model order plus cullUnobservable (modToObs.cu:682-709) in one launch: what the multi-model loop
+// otherwise does with one replay launch per model and one cull launch, on its critical chain
+struct ReplayMultiArgs {
+    int n;
+    ModelView m[DARTK_MAX_MODELS];
+    unsigned long long off[DARTK_MAX_MODELS];       // each model's slice of the trace buffer (floats)
+};
+static_assert(sizeof(ReplayMultiArgs) <= 3584, "ReplayMultiArgs is passed by value as a kernel argument");
+
+__global__ void __launch_bounds__(256)
+raycast_replay_multi_kernel(float flx, float fly, float ppx, float ppy, int width, int height, ReplayMultiArgs a,
+                            const float *__restrict__ rayBuf, float4 *__restrict__ prediction, const float4 *__restrict__ obs, int ow,
+                            int oh) {
+    __shared__ float sT[RC_REPLAY_SDFS * 24];
+    const int nPix = width * height;
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = index < nPix;
+    const int x = valid ? index % width : 0, y = valid ? index / width : 0;
+    float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) { pr = prediction[index]; pr.z = 0; pr.w = -1; }    // model 0 starts the map (x, y keep what the map held, as there)
+    for (int mi = 0; mi < a.n; ++mi) {
+        const ModelView &m = a.m[mi];
+        const float2 *trace = reinterpret_cast<const float2 *>(rayBuf + a.off[mi]);
+        float closestT = 10000;
+        for (int s0 = 0; s0 < m.nSdfs; s0 += RC_REPLAY_SDFS) {
+            const int nc = min(RC_REPLAY_SDFS, m.nSdfs - s0);
+            __syncthreads();
+            replay_stage_transforms(m, s0, nc, sT);
+            __syncthreads();
+            if (valid) replay_pixel(pr, closestT, x, y, index, nPix, mi, s0, nc, sT, trace, flx, fly, ppx, ppy);
+        }
+    }
+    if (valid) {
+        const int ox = x * ow / width, oy = y * oh / height;
+        const int oi = ox + oy * ow;
+        if (obs[oi].w <= 0 || obs[oi + 1].w <= 0 || obs[oi + ow].w <= 0 || obs[oi + ow + 1].w <= 0) pr.z = 0;
+        prediction[index] = pr;
+    }
+}
+
 // the trace alone (the replay is done by the consumer: ne_mod2obs_kernel<.., REPLAY = true>)
 static int launch_raycast_trace(float flx, float fly, float ppx, float ppy, int width, int height, const ModelView &m, float levelSet,
                                 Workspace *ws, hipStream_t st, size_t bufOffset = 0) {
@@ -624,6 +664,24 @@ int gn_launch_raycast_trace_at(float flx, float fly, float ppx, float ppy, int w
     if (rc) return rc;
     DARTK_REQUIRE(bufOffset + 2 * (size_t)width * height * m.nSdfs <= ws->rayFloats, "trace buffer was not reserved");
     return launch_raycast_trace(flx, fly, ppx, ppy, width, height, m, 0.0f, ws, st, bufOffset);
+}
+int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float ppy, int width, int height, int nModels,
+                                        Model *const *mods, const size_t *bufOffsets, float *d_prediction, const float *d_obs, int ow,
+                                        int oh, hipStream_t st) {
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    DARTK_REQUIRE(nModels >= 1 && nModels <= DARTK_MAX_MODELS, "bad model count %d", nModels);
+    DARTK_REQUIRE(ow >= 2 && oh >= 2, "observation map too small");
+    ReplayMultiArgs a;
+    a.n = nModels;
+    for (int m = 0; m < nModels; ++m) { a.m[m] = mods[m]->v; a.off[m] = bufOffsets[m]; }
+    const size_t nPix = (size_t)width * height;
+    ProfScope ps2(DARTK_PROF_RAYCAST_REPLAY, st);
+    hipLaunchKernelGGL(raycast_replay_multi_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height,
+                       a, (const float *)ws->rayBuf, (float4 *)d_prediction, (const float4 *)d_obs, ow, oh);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
 }
 int gn_launch_raycast_replay_at(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                                 float *d_prediction, size_t bufOffset, hipStream_t st) {

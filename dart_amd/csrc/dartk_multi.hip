@@ -339,12 +339,8 @@ int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *
                 DARTK_HIP(hipEventRecord(ws->evTrace, stC));
                 DARTK_HIP(hipStreamWaitEvent(st, ws->evTrace, 0));      // after this stream's own trace, which takes as long
             }
-            for (int m = 0; m < n; ++m) {
-                rc = gn_launch_raycast_replay_at(o->predFl[0], o->predFl[1], ppx, ppy, o->predWidth, o->predHeight, m, mods[m]->v,
-                                                 d_prediction, traceOff[m], st);
-                if (rc) return rc;
-            }
-            rc = gn_launch_cull(d_prediction, o->predWidth, o->predHeight, d_vert, width, height, st);
+            rc = gn_launch_raycast_replay_cull_multi(o->predFl[0], o->predFl[1], ppx, ppy, o->predWidth, o->predHeight, n, mods, traceOff,
+                                                     d_prediction, d_vert, width, height, st);
             if (rc) return rc;
             DARTK_HIP(hipMemsetAsync(d_countB, 0, n * sizeof(int), st));
             for (int m = 0; m < n; ++m) {   // reduced wrappers use the model's current T_mc, the full one T_obsSdf_c (modToObs.cu:851-988 vs :713-780)
