@@ -22,10 +22,22 @@ def articulated(name, resolution=0.005, padding=0.10):
     return _cache[key]
 
 
+def kat1_vertex_map(order="as_compiled"):
+    """The reference kernel test's OWN observation map (test_obs_to_mod_kernels.cpp:42-53): 10x10, drawn from libstdc++'s
+    std::default_random_engine / bernoulli_distribution(0.8) / normal_distribution<float>(0, 0.1) by the committed generator
+    tests/golden/gen_kat1_inputs.cpp (fixture tests/golden/kat1_inputs.json, floats stored as bit patterns). `order`: which
+    argument evaluation order filled x, y, z ("as_compiled" = g++, the reference's host compiler; "left_to_right")."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat1_inputs.json")) as fh:
+        d = json.load(fh)
+    v = np.array(d[order], dtype=np.uint32).view(F)
+    return np.ascontiguousarray(v.reshape(d["height"], d["width"], 4))
+
+
 def random_vertex_map(w, h, seed, sigma=0.1, p_valid=0.8, center=(0, 0, 0)):
-    """The reference kernel test's observation (test_obs_to_mod_kernels.cpp:42-53): points ~ N(0, sigma^2) per
-    axis, 80 % valid. (It draws from libstdc++'s default engine; a seeded numpy generator is used here: the
-    checked properties do not depend on the particular draw.)"""
+    """Larger maps with the statistics of the reference kernel test's observation (points ~ N(0, sigma^2) per axis, 80 %
+    valid) from a seeded numpy generator; the reference's own 10x10 draw is kat1_vertex_map()."""
     rng = np.random.default_rng(seed)
     v = np.zeros((h, w, 4), dtype=F)
     valid = rng.random((h, w)) < p_valid

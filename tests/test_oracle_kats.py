@@ -7,6 +7,7 @@ These run on the CPU (no GPU)."""
 import ctypes as C
 
 import numpy as np
+import pytest
 
 import oracle_lib as O
 import scenes
@@ -62,6 +63,41 @@ def test_kat1_sphere_association_matches_analytic():
         assert n_assoc > 0
         assert len(pts) == (dbg["da"] >= 0).sum()
         assert np.all(np.diff(pts["index"]) > 0)
+
+
+def kat1_reference_asserts(vert, da, err, dist_thr=0.05, radius=0.1, res=0.005):
+    """The checks of test_obs_to_mod_kernels.cpp:87-102, verbatim in meaning: invalid pixel or |dist| > threshold => DA -1 and
+    NaN error; otherwise DA 0 and |dist - error| <= res/8 (EXPECT_NEAR). dist = length(float3) - radius in fp32 like the test."""
+    n_assoc = 0
+    p = vert.reshape(-1, 4)
+    da, err = np.asarray(da).reshape(-1), np.asarray(err).reshape(-1)
+    for i in range(len(p)):
+        if p[i, 3] == 0:
+            assert da[i] == -1 and np.isnan(err[i]), i
+            continue
+        x, y, z = p[i, :3]
+        dist = F(np.sqrt(F(F(F(x * x) + F(y * y)) + F(z * z)))) - F(radius)
+        if abs(dist) > F(dist_thr):
+            assert da[i] == -1 and np.isnan(err[i]), (i, dist, da[i], err[i])
+        else:
+            assert da[i] == 0, (i, dist, da[i])
+            assert abs(float(dist) - float(err[i])) <= res / 8, (i, dist, err[i])
+            n_assoc += 1
+    return n_assoc
+
+
+@pytest.mark.parametrize("order", ["as_compiled", "left_to_right"])
+def test_kat1_reference_draw(order):
+    """KAT 1 on the reference's own inputs (libstdc++ draw, tests/golden/kat1_inputs.json) with the reference's asserts."""
+    m = scenes.sphere()
+    om = O.OModel(m)
+    _, T_fm = om.fk(np.zeros(0, dtype=F))
+    vert = scenes.kat1_vertex_map(order)
+    assert vert.shape == (10, 10, 4) and int((vert[..., 3] > 0).sum()) == 80
+    norm = np.zeros_like(vert)
+    pts, dbg = O.assoc_single(vert, norm, om, se3.identity(), T_fm, dist_thr=0.05)
+    n = kat1_reference_asserts(vert, dbg["da"], dbg["err"])
+    assert n == len(pts) and n > 10
 
 
 def _fd_check(name, mode):
