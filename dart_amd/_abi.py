@@ -147,6 +147,7 @@ def lib():
         "dartk_assoc_single": [vp, vp, C.c_int, C.c_int, vp, C.c_float, C.c_float, C.c_float, c_float_p, vp, vp, c_int_p, vp, vp, vp, vp],
         "dartk_assoc_multi": [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), c_float_p, c_float_p, c_float_p, C.POINTER(vp), vp, vp, vp, vp],
         "dartk_ne_obs2mod": [C.c_int, vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp],
+        "dartk_ne_obs2mod_noalloc": [C.c_int, vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp],
         "dartk_ne_obs2mod_reduced": [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp],
         "dartk_ne_obs2mod_parammap": [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp],
         "dartk_raycast_prediction": [C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp],

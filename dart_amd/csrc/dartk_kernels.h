@@ -10,6 +10,7 @@ namespace dartk {
 static constexpr int NE_BLOCK = 128;   // lanes (= points per tile) of every normal-equation workgroup
 
 int ensure_partials(Workspace *w, size_t floats);
+int noalloc_scratch(float **out);      // dartk_obs2mod.hip: device address of the no-allocation entry point's scratch array
 int get_multi_args_buffer(void **d_ptr, size_t bytes);
 int ensure_ray_buf(Workspace *w, size_t floats);
 int ensure_valid_idx(Workspace *w, size_t ints);

@@ -175,7 +175,9 @@ int dartk_init(int device) {
     DARTK_REQUIRE(device >= 0 && device < n, "device %d out of range (%d devices)", device, n);
     DARTK_HIP(hipSetDevice(device));
     Workspace *w;
-    return get_workspace(&w);
+    int rc = get_workspace(&w);
+    if (rc) return rc;
+    return noalloc_scratch(nullptr);        // resolve this device's address of the no-allocation scratch array once
 }
 
 int dartk_buf_alloc(void **d_ptr, size_t bytes) {

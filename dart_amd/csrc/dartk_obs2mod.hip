@@ -294,6 +294,67 @@ int gn_launch_ne_obs2mod_dev(int red, int fullDims, int redDims, const float *d_
     return launch_ne_obs2mod_dev<0>(fullDims, fullDims, d_vert, mod, huberDelta, d_pts, d_count, maxElements, nullptr, nullptr, d_result, st);
 }
 
+// -----------------------------------------------------------------------------------------------------
+// The same normal equations for callers that cannot allocate (code under HIP graph capture, tight serving loops):
+// dartk_ne_obs2mod_noalloc. The partial-system slabs -- the one scratch buffer of this term, which dartk_ne_obs2mod takes
+// from the library's hipMalloc'ed workspace -- live in a file-scope device array of a fixed, modest size (kNoAllocMaxBlocks
+// slabs of a system of up to kNoAllocMaxDims dimensions = 561 KiB per GPU, held until the process ends). `scratch` itself is a
+// host-side stand-in for the symbol: the device address is looked up once per device (hipGetSymbolAddress, at dartk_init or
+// at the entry point's first call on that device) and only that pointer is ever handed to kernels. Nothing has to be
+// cleared between calls: every launched workgroup overwrites its whole slab and the reduction reads exactly the slabs of
+// this launch. Calls that overlap on one GPU share the array and race.
+// -----------------------------------------------------------------------------------------------------
+static constexpr int kNoAllocMaxDims = 32;
+static constexpr int kNoAllocMaxBlocks = 256;
+static constexpr size_t kNoAllocFloats = (size_t)kNoAllocMaxBlocks * sys_size(kNoAllocMaxDims);
+static __device__ __align__(256) float scratch[kNoAllocFloats];
+static float *g_scratchPtr[16] = {nullptr};       // per device: each GPU holds its own copy of the array at its own address
+
+// device address of this device's `scratch` (the device must be current); no allocation
+int noalloc_scratch(float **out) {
+    int dev = 0;
+    DARTK_HIP(hipGetDevice(&dev));
+    DARTK_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+    if (!g_scratchPtr[dev]) {
+        float *ptr = nullptr;
+        DARTK_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+        DARTK_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned a null address for the no-allocation scratch array");
+        g_scratchPtr[dev] = ptr;
+    }
+    if (out) *out = g_scratchPtr[dev];
+    return DARTK_OK;
+}
+
+static int launch_ne_obs2mod_noalloc(int dims, const float *d_vert, Model *mod, float huberDelta, const dartk_da_point *d_pts,
+                                     int nElements, float *d_result, hipStream_t st) {
+    const ModelView &m = mod->v;
+    DARTK_REQUIRE(dims <= kNoAllocMaxDims, "dartk_ne_obs2mod_noalloc supports at most %d dimensions (fixed scratch array), got %d; use dartk_ne_obs2mod",
+                  kNoAllocMaxDims, dims);
+    DARTK_REQUIRE(dims == 6 + m.nJoints, "dims %d does not match the model's 6+%d", dims, m.nJoints);
+    DARTK_REQUIRE(nElements >= 0, "negative element count");
+    const int S = sys_size(dims);
+    if (nElements <= 10) {    // obsToMod.cu:644-646: memset only
+        DARTK_HIP(hipMemsetAsync(d_result, 0, S * sizeof(float), st));
+        return DARTK_OK;
+    }
+    float *slabs = nullptr;
+    int rc = noalloc_scratch(&slabs);
+    if (rc) return rc;
+    const int nTiles = (nElements + NE_BLOCK - 1) / NE_BLOCK;
+    const int nBlocks = nTiles < kNoAllocMaxBlocks ? nTiles : kNoAllocMaxBlocks;      // the kernel strides over the tiles
+    const size_t ldsBytes = ne_obs2mod_lds_bytes(m, dims, 0);
+    DARTK_REQUIRE(ldsBytes <= 64 * 1024, "LDS requirement %zu exceeds the 64 KiB a launch gets without an attribute call", ldsBytes);
+    const float4 *vert = reinterpret_cast<const float4 *>(d_vert);
+    if (S <= 3 * NE_BLOCK)
+        hipLaunchKernelGGL((ne_obs2mod_kernel<3, 0>), dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, nElements, m, huberDelta,
+                           dims, (const float *)nullptr, (const int *)nullptr, slabs, (const int *)nullptr);
+    else
+        hipLaunchKernelGGL((ne_obs2mod_kernel<6, 0>), dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, nElements, m, huberDelta,
+                           dims, (const float *)nullptr, (const int *)nullptr, slabs, (const int *)nullptr);
+    DARTK_HIP(hipGetLastError());
+    return launch_reduce_slabs(slabs, nBlocks, S, d_result, 1, st);
+}
+
 // multi-model association for the device-resident loop: the argument block is uploaded once per optimizePoses call
 // (the ModelViews point at pose arrays that are updated in place), then one launch per iteration
 int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr, const float *planeOffset, const float *pn3,
@@ -403,6 +464,14 @@ int dartk_ne_obs2mod(int dims, const float *d_vert, int width, int height, dartk
     DARTK_REQUIRE(mod && d_vert && d_pts && d_result, "dartk_ne_obs2mod: null argument");
     DARTK_REQUIRE(nElements <= width * height, "nElements %d exceeds the map size", nElements);
     return launch_ne_obs2mod<0>(dims, dims, d_vert, mod, huberDelta, d_pts, nElements, nullptr, nullptr, d_result, as_stream(stream));
+}
+
+int dartk_ne_obs2mod_noalloc(int dims, const float *d_vert, int width, int height, dartk_model_t h, float huberDelta,
+                             const dartk_da_point *d_pts, int nElements, float *d_result, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_vert && d_pts && d_result, "dartk_ne_obs2mod_noalloc: null argument");
+    DARTK_REQUIRE(width > 0 && height > 0 && nElements <= width * height, "nElements %d exceeds the map size", nElements);
+    return launch_ne_obs2mod_noalloc(dims, d_vert, mod, huberDelta, d_pts, nElements, d_result, as_stream(stream));
 }
 
 int dartk_ne_obs2mod_reduced(int dims, int redDims, const float *d_A, const float *d_vert, int width, int height,

@@ -155,15 +155,19 @@ def sys_len(dims):
     return dims + dims * (dims + 1) // 2 + 1
 
 
-def norm_eqns_obs_to_mod(vert, model, pts, n_elements, huber_delta=0.02, reduction=None, result=None):
+def norm_eqns_obs_to_mod(vert, model, pts, n_elements, huber_delta=0.02, reduction=None, result=None, no_alloc=False):
     """normEqnsObsToMod{,Reduced,ParamMap} (obsToMod.h:12-45). reduction = None | ("linear", A tensor, redDims) |
-    ("map", mapping tensor, redDims). Returns the packed system as a CUDA tensor."""
+    ("map", mapping tensor, redDims). Returns the packed system as a CUDA tensor. no_alloc: dartk_ne_obs2mod_noalloc, the
+    variant that allocates nothing inside the library (then pass `result`, or the output tensor is the only allocation)."""
     h, w = vert.shape[0], vert.shape[1]
     dims = model.dims
     rd = dims if reduction is None else reduction[2]
     if result is None:
         result = torch.empty(sys_len(rd), dtype=torch.float32, device=vert.device)
-    if reduction is None:
+    if no_alloc:
+        assert reduction is None
+        check(lib().dartk_ne_obs2mod_noalloc(dims, _ptr(vert), w, h, model.handle, huber_delta, _ptr(pts), n_elements, _ptr(result), _stream()))
+    elif reduction is None:
         check(lib().dartk_ne_obs2mod(dims, _ptr(vert), w, h, model.handle, huber_delta, _ptr(pts), n_elements, _ptr(result), _stream()))
     elif reduction[0] == "linear":
         check(lib().dartk_ne_obs2mod_reduced(dims, rd, _ptr(reduction[1]), _ptr(vert), w, h, model.handle, huber_delta,

@@ -107,6 +107,14 @@ int dartk_assoc_multi(const float *d_vert, const float *d_norm, int width, int h
 /* normEqnsObsToMod, obsToMod.h:12-21 / obsToMod.cu:621-697 (system zeroed; kernel only if nElements > 10). */
 int dartk_ne_obs2mod(int dims, const float *d_vert, int width, int height, dartk_model_t m, float huberDelta,
                      const dartk_da_point *d_pts, int nElements, float *d_result, void *stream);
+/* NO COUNTERPART IN THE REFERENCE. dartk_ne_obs2mod for callers that cannot allocate (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc): same arguments, same kernels, same result, but the partial-system scratch
+ * lives in a fixed device array inside the library instead of its hipMalloc'ed workspace, and the call performs no hipMalloc /
+ * hipFree / allocating library call. Limits: dims <= 32 (the array holds 256 partial systems of that size, 561 KiB per GPU,
+ * kept until the process ends); larger models are rejected with DARTK_ERR_INVALID. All calls on one GPU share the array: calls
+ * that overlap on one GPU (two streams, two threads) race -- serialise them. */
+int dartk_ne_obs2mod_noalloc(int dims, const float *d_vert, int width, int height, dartk_model_t m, float huberDelta,
+                             const dartk_da_point *d_pts, int nElements, float *d_result, void *stream);
 /* normEqnsObsToModReduced, obsToMod.h:23-33 / obsToMod.cu:699-757. d_dtheta_dalpha: [(dims-6)*(redDims-6)],
  * row = full joint (pose.cpp:66-73). */
 int dartk_ne_obs2mod_reduced(int dims, int redDims, const float *d_dtheta_dalpha, const float *d_vert, int width,
