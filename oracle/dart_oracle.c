@@ -10,6 +10,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ------------------------------------------------------------------------------------------------
  * small vector helpers (CUDA samples' helper_math.h semantics, which the reference includes)
@@ -152,6 +155,13 @@ static inline float grid_at(const orc_grid *g, int x, int y, int z) {
 }
 
 /* trilinear-lookup counters by caller category: feed the algorithmic-bytes figures of bench.py */
+/* Worker threads of the per-pixel / per-point loops (OpenMP). 1 (the default) is the plain serial restatement every parity
+ * test runs; bench.py's all-cores CPU baseline raises it. Pixels are independent; partial systems are kept per thread over a
+ * contiguous chunk and added in thread order, so a given thread count is reproducible and one thread is the serial code. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+int orc_get_threads(void) { return g_threads; }
+
 static long long g_lookups[ORC_STAT_CATEGORIES];
 static int g_cat = 0;
 static int g_stats_on = 0;
@@ -300,68 +310,98 @@ void orc_model_jacobian_3d(const orc_model *m, const float *T_fm, const float *T
 /* ------------------------------------------------------------------------------------------------
  * obs -> mod data association
  * ---------------------------------------------------------------------------------------------- */
+/* one pixel of gpu_errorAndDataAssociationObsToMod (obsToMod.cu:12-114): returns 1 when the pixel is associated */
+static int assoc_single_pixel(int index, const float *vert, const float *norm, const orc_model *m, const float *T_mc,
+                              const float *T_fm, float distanceThreshold, float normThreshold, float planeOffset,
+                              const float *planeNormal, int *gridOut, float *errOut, int32_t *dbgDA, float *dbgErr,
+                              float *dbgNorm) {
+    stat_enter(ORC_STAT_ASSOC);
+    if (dbgDA) dbgDA[index] = -1;
+    if (dbgErr) dbgErr[index] = NAN;
+    if (dbgNorm) { dbgNorm[4 * index] = dbgNorm[4 * index + 1] = dbgNorm[4 * index + 2] = dbgNorm[4 * index + 3] = 0; }
+    const float *xc = vert + 4 * index;
+    if (!(xc[3] > 0)) return 0;
+    float xm[4];
+    se3_apply4(T_mc, xc, xm);
+    if (!(dot3(xm, planeNormal) >= planeOffset)) return 0;
+
+    float sdfError = 1e20f;
+    int grid = -1;
+    for (int g = 0; g < m->n_sdfs; ++g) {
+        const int f = m->sdf_frame[g];
+        float xf[4], xg[3];
+        se3_apply4(T_fm + 12 * f, xm, xf);
+        const orc_grid sdf = model_sdf(m, g);
+        orc_grid_coords(&sdf, xf, xg);
+        if (!orc_grid_in_bounds_gradient_interp(&sdf, xg)) continue;
+        const float d = orc_grid_value_interp(&sdf, xg) * sdf.resolution;
+        if (d < sdfError) { sdfError = d; grid = g; }
+    }
+    if (sdfError * sdfError > distanceThreshold * distanceThreshold) return 0;
+
+    {
+        const int f = m->sdf_frame[grid];
+        float xf[4], xg[3], gr[3];
+        se3_apply4(T_fm + 12 * f, xm, xf);
+        const orc_grid sdf = model_sdf(m, grid);
+        orc_grid_coords(&sdf, xf, xg);
+        stat_enter(ORC_STAT_ASSOC_GRAD);
+        orc_grid_gradient_interp(&sdf, xg, gr);
+        stat_enter(ORC_STAT_ASSOC);
+        /* nPred = -1 * (SE3Invert(T_fm[f]*T_mc) * normalize(float4(grad,0))), obsToMod.cu:84 */
+        float T_fc[12], T_cf[12];
+        orc_se3_mul(T_fm + 12 * f, T_mc, T_fc);
+        orc_se3_invert(T_fc, T_cf);
+        float g4[4] = {gr[0], gr[1], gr[2], 0};
+        const float invLen = 1.0f / sqrtf(g4[0] * g4[0] + g4[1] * g4[1] + g4[2] * g4[2] + g4[3] * g4[3]);
+        g4[0] *= invLen; g4[1] *= invLen; g4[2] *= invLen; g4[3] *= invLen;
+        float nPred[4];
+        se3_apply4(T_cf, g4, nPred);
+        nPred[0] = -1 * nPred[0]; nPred[1] = -1 * nPred[1]; nPred[2] = -1 * nPred[2]; nPred[3] = -1 * nPred[3];
+        if (dbgNorm) memcpy(dbgNorm + 4 * index, nPred, 4 * sizeof(float));
+        const float *v = norm + 4 * index;
+        if (v[3] > 0.0) {
+            const float d = nPred[0] * v[0] + nPred[1] * v[1] + nPred[2] * v[2] + nPred[3] * 0.0f;
+            if (d < normThreshold) return 0;
+        }
+    }
+    if (dbgDA) dbgDA[index] = grid;
+    if (dbgErr) dbgErr[index] = sdfError;
+    *gridOut = grid; *errOut = sdfError;
+    return 1;
+}
+
 int orc_assoc_single(const float *vert, const float *norm, int width, int height, const orc_model *m,
                      const float *T_mc, const float *T_fm, float distanceThreshold, float normThreshold,
                      float planeOffset, const float *planeNormal, orc_da_point *pts,
                      int32_t *dbgDA, float *dbgErr, float *dbgNorm) {
     int count = 0;
     const int oldcat = stat_enter(ORC_STAT_ASSOC);
-    for (int index = 0; index < width * height; ++index) {
-        if (dbgDA) dbgDA[index] = -1;
-        if (dbgErr) dbgErr[index] = NAN;
-        if (dbgNorm) { dbgNorm[4 * index] = dbgNorm[4 * index + 1] = dbgNorm[4 * index + 2] = dbgNorm[4 * index + 3] = 0; }
-        const float *xc = vert + 4 * index;
-        if (!(xc[3] > 0)) continue;
-        float xm[4];
-        se3_apply4(T_mc, xc, xm);
-        if (!(dot3(xm, planeNormal) >= planeOffset)) continue;
-
-        float sdfError = 1e20f;
-        int grid = -1;
-        for (int g = 0; g < m->n_sdfs; ++g) {
-            const int f = m->sdf_frame[g];
-            float xf[4], xg[3];
-            se3_apply4(T_fm + 12 * f, xm, xf);
-            const orc_grid sdf = model_sdf(m, g);
-            orc_grid_coords(&sdf, xf, xg);
-            if (!orc_grid_in_bounds_gradient_interp(&sdf, xg)) continue;
-            const float d = orc_grid_value_interp(&sdf, xg) * sdf.resolution;
-            if (d < sdfError) { sdfError = d; grid = g; }
+    const int nPix = width * height;
+    if (g_threads <= 1) {
+        for (int index = 0; index < nPix; ++index) {
+            int grid; float err;
+            if (!assoc_single_pixel(index, vert, norm, m, T_mc, T_fm, distanceThreshold, normThreshold, planeOffset, planeNormal,
+                                    &grid, &err, dbgDA, dbgErr, dbgNorm)) continue;
+            pts[count].index = index; pts[count].dataAssociation = grid; pts[count].error = err;
+            ++count;
         }
-        if (sdfError * sdfError > distanceThreshold * distanceThreshold) continue;
-
-        {
-            const int f = m->sdf_frame[grid];
-            float xf[4], xg[3], gr[3];
-            se3_apply4(T_fm + 12 * f, xm, xf);
-            const orc_grid sdf = model_sdf(m, grid);
-            orc_grid_coords(&sdf, xf, xg);
-            stat_enter(ORC_STAT_ASSOC_GRAD);
-            orc_grid_gradient_interp(&sdf, xg, gr);
-            stat_enter(ORC_STAT_ASSOC);
-            /* nPred = -1 * (SE3Invert(T_fm[f]*T_mc) * normalize(float4(grad,0))), obsToMod.cu:84 */
-            float T_fc[12], T_cf[12];
-            orc_se3_mul(T_fm + 12 * f, T_mc, T_fc);
-            orc_se3_invert(T_fc, T_cf);
-            float g4[4] = {gr[0], gr[1], gr[2], 0};
-            const float invLen = 1.0f / sqrtf(g4[0] * g4[0] + g4[1] * g4[1] + g4[2] * g4[2] + g4[3] * g4[3]);
-            g4[0] *= invLen; g4[1] *= invLen; g4[2] *= invLen; g4[3] *= invLen;
-            float nPred[4];
-            se3_apply4(T_cf, g4, nPred);
-            nPred[0] = -1 * nPred[0]; nPred[1] = -1 * nPred[1]; nPred[2] = -1 * nPred[2]; nPred[3] = -1 * nPred[3];
-            if (dbgNorm) memcpy(dbgNorm + 4 * index, nPred, 4 * sizeof(float));
-            const float *v = norm + 4 * index;
-            if (v[3] > 0.0) {
-                const float d = nPred[0] * v[0] + nPred[1] * v[1] + nPred[2] * v[2] + nPred[3] * 0.0f;
-                if (d < normThreshold) continue;
-            }
+    } else {    /* pixels are independent; the list keeps pixel order (the reference's atomic append has no order) */
+        int *grids = (int *)malloc(sizeof(int) * (size_t)nPix);
+        float *errs = (float *)malloc(sizeof(float) * (size_t)nPix);
+#pragma omp parallel for schedule(static, 1024) num_threads(g_threads)
+        for (int index = 0; index < nPix; ++index) {
+            grids[index] = -1;
+            int grid; float err;
+            if (assoc_single_pixel(index, vert, norm, m, T_mc, T_fm, distanceThreshold, normThreshold, planeOffset, planeNormal,
+                                   &grid, &err, dbgDA, dbgErr, dbgNorm)) { grids[index] = grid; errs[index] = err; }
         }
-        if (dbgDA) dbgDA[index] = grid;
-        if (dbgErr) dbgErr[index] = sdfError;
-        pts[count].index = index;
-        pts[count].dataAssociation = grid;
-        pts[count].error = sdfError;
-        ++count;
+        for (int index = 0; index < nPix; ++index) {
+            if (grids[index] < 0) continue;
+            pts[count].index = index; pts[count].dataAssociation = grids[index]; pts[count].error = errs[index];
+            ++count;
+        }
+        free(grids); free(errs);
     }
     stat_enter(oldcat);
     return count;
@@ -472,39 +512,57 @@ void orc_ne_obs2mod(const float *vert, const orc_model *m, const float *T_mc, co
     sys_acc s = sys_new(dims);
     const int oldcat = stat_enter(ORC_STAT_NE_OBS2MOD);
     if (nPoints > 10) { /* obsToMod.cu:646,723,783 */
-        float *de = (float *)malloc(sizeof(float) * (size_t)(fullDims + dims));
-        float *Jr = de + fullDims;
-        for (int k = 0; k < nPoints; ++k) {
-            float xm[4], xf[4], xg[3], gf[3], gm[3];
-            se3_apply4(T_mc, vert + 4 * pts[k].index, xm);
-            const int g = pts[k].dataAssociation;
-            const int obsFrame = m->sdf_frame[g];
-            se3_apply4(T_fm + 12 * obsFrame, xm, xf);
-            const orc_grid sdf = model_sdf(m, g);
-            orc_grid_coords(&sdf, xf, xg);
-            orc_grid_gradient_interp(&sdf, xg, gf);
-            se3_rotate3(T_mf + 12 * obsFrame, gf, gm);
-            orc_error_jacobian(m, T_fm, T_mf, xm, obsFrame, gm, 0, de);
-            const float *J = de;
-            if (reduction) { reduce_jacobian(reduction, 6, fullDims, redDims, de, dtheta_dalpha, mapping, Jr); J = Jr; }
-            const float err = pts[k].error;
-            if (fabsf(err) < huberDelta) {
-                sys_add_squared(&s, -err, J);
-            } else { /* Huber outlier branch, obsToMod.cu:318-332 (full) / :404-415 (reduced: no JTJ) */
-                float v = huberDelta;
-                if (err < 0) v = -v;
-                double *JTr = s.acc, *JTJ = s.acc + dims, *e = s.acc + dims + jtj_size(dims);
-                for (int i = 0; i < dims; ++i) {
-                    if (J[i] == 0.0f) continue;
-                    JTr[i] += (float)(v * -J[i]);
-                    if (!reduction) {
-                        for (int j = 0; j <= i; ++j) { float v2 = J[i] * J[j]; JTJ[((i * (i + 1)) >> 1) + j] += v2; }
+        const int nT = g_threads > 1 ? g_threads : 1;
+        const int nSys = dims + jtj_size(dims) + 1;
+        double *part = nT > 1 ? (double *)calloc((size_t)nT * nSys, sizeof(double)) : NULL;
+#pragma omp parallel num_threads(nT) if (nT > 1)
+        {
+            int tid = 0;
+#ifdef _OPENMP
+            tid = omp_get_thread_num();
+#endif
+            stat_enter(ORC_STAT_NE_OBS2MOD);
+            sys_acc st = s;
+            if (nT > 1) st.acc = part + (size_t)tid * nSys;
+            const int k0 = (int)((long long)nPoints * tid / nT), k1 = (int)((long long)nPoints * (tid + 1) / nT);
+            float *de = (float *)malloc(sizeof(float) * (size_t)(fullDims + dims));
+            float *Jr = de + fullDims;
+            for (int k = k0; k < k1; ++k) {
+                float xm[4], xf[4], xg[3], gf[3], gm[3];
+                se3_apply4(T_mc, vert + 4 * pts[k].index, xm);
+                const int g = pts[k].dataAssociation;
+                const int obsFrame = m->sdf_frame[g];
+                se3_apply4(T_fm + 12 * obsFrame, xm, xf);
+                const orc_grid sdf = model_sdf(m, g);
+                orc_grid_coords(&sdf, xf, xg);
+                orc_grid_gradient_interp(&sdf, xg, gf);
+                se3_rotate3(T_mf + 12 * obsFrame, gf, gm);
+                orc_error_jacobian(m, T_fm, T_mf, xm, obsFrame, gm, 0, de);
+                const float *J = de;
+                if (reduction) { reduce_jacobian(reduction, 6, fullDims, redDims, de, dtheta_dalpha, mapping, Jr); J = Jr; }
+                const float err = pts[k].error;
+                if (fabsf(err) < huberDelta) {
+                    sys_add_squared(&st, -err, J);
+                } else { /* Huber outlier branch, obsToMod.cu:318-332 (full) / :404-415 (reduced: no JTJ) */
+                    float v = huberDelta;
+                    if (err < 0) v = -v;
+                    double *JTr = st.acc, *JTJ = st.acc + dims, *e = st.acc + dims + jtj_size(dims);
+                    for (int i = 0; i < dims; ++i) {
+                        if (J[i] == 0.0f) continue;
+                        JTr[i] += (float)(v * -J[i]);
+                        if (!reduction) {
+                            for (int j = 0; j <= i; ++j) { float v2 = J[i] * J[j]; JTJ[((i * (i + 1)) >> 1) + j] += v2; }
+                        }
                     }
+                    *e += (float)(huberDelta * (fabsf(err) - 0.5 * huberDelta));
                 }
-                *e += (float)(huberDelta * (fabsf(err) - 0.5 * huberDelta));
             }
+            free(de);
         }
-        free(de);
+        if (part) {
+            for (int t = 0; t < nT; ++t) for (int i = 0; i < nSys; ++i) s.acc[i] += part[(size_t)t * nSys + i];
+            free(part);
+        }
     }
     stat_enter(oldcat);
     sys_emit(&s, result);
@@ -534,7 +592,9 @@ void orc_raycast_prediction(float flx, float fly, float ppx, float ppy, int widt
     float T_cm[12];
     orc_se3_invert(T_mc, T_cm);
     const int oldcat = stat_enter(ORC_STAT_RAYCAST);
+#pragma omp parallel for schedule(dynamic, 2) num_threads(g_threads) if (g_threads > 1)
     for (int y = 0; y < height; ++y) for (int x = 0; x < width; ++x) {
+        stat_enter(ORC_STAT_RAYCAST);
         const int index = x + y * width;
         float *pr = prediction + 4 * index;
         if (modelNum == 0) { pr[2] = 0; pr[3] = -1; }
@@ -620,6 +680,7 @@ void orc_cull_unobservable(float *pred, int pw, int ph, const float *obs, int ow
 void orc_splat_obs_sdf(const float *vert, int width, int height, const float *T_cm, const orc_grid *g,
                        float focalLength, float *data) {
     const float truncVal = 1000.0f;
+#pragma omp parallel for num_threads(g_threads) if (g_threads > 1)
     for (int z = 0; z < g->dim[2]; ++z) for (int y = 0; y < g->dim[1]; ++y) for (int x = 0; x < g->dim[0]; ++x) {
         float p[3] = {g->offset[0] + g->resolution * (float)x, g->offset[1] + g->resolution * (float)y,
                       g->offset[2] + g->resolution * (float)z};
@@ -665,16 +726,22 @@ static void dt_1d(const float *fIn, float *fOut, int len, int stride, int takeSq
 
 void orc_distance_transform_3d(float *in, float *out, int width, int height, int depth, int takeSqrt) {
     int maxLen = width > height ? width : height; if (depth > maxLen) maxLen = depth;
-    float *z = (float *)malloc(sizeof(float) * (size_t)(maxLen + 1));
-    int *v = (int *)malloc(sizeof(int) * (size_t)maxLen);
-    /* x-direction: in -> out (rows = height*depth, outer stride width, inner 1) */
-    for (int t = 0; t < height * depth; ++t) dt_1d(in + (size_t)t * width, out + (size_t)t * width, width, 1, 0, z, v);
-    /* z-direction: out -> in (num = width*height, outer stride 1, inner width*height) */
-    for (int t = 0; t < width * height; ++t) dt_1d(out + t, in + t, depth, width * height, 0, z, v);
-    /* y-direction: in -> out (a<width, b<depth; strides 1, width*height; inner width) */
-    for (int b = 0; b < depth; ++b) for (int a = 0; a < width; ++a)
-        dt_1d(in + a + (size_t)b * width * height, out + a + (size_t)b * width * height, height, width, takeSqrt, z, v);
-    free(z); free(v);
+#pragma omp parallel num_threads(g_threads) if (g_threads > 1)
+    {
+        float *z = (float *)malloc(sizeof(float) * (size_t)(maxLen + 1));
+        int *v = (int *)malloc(sizeof(int) * (size_t)maxLen);
+        /* x-direction: in -> out (rows = height*depth, outer stride width, inner 1) */
+#pragma omp for
+        for (int t = 0; t < height * depth; ++t) dt_1d(in + (size_t)t * width, out + (size_t)t * width, width, 1, 0, z, v);
+        /* z-direction: out -> in (num = width*height, outer stride 1, inner width*height) */
+#pragma omp for
+        for (int t = 0; t < width * height; ++t) dt_1d(out + t, in + t, depth, width * height, 0, z, v);
+        /* y-direction: in -> out (a<width, b<depth; strides 1, width*height; inner width) */
+#pragma omp for
+        for (int b = 0; b < depth; ++b) for (int a = 0; a < width; ++a)
+            dt_1d(in + a + (size_t)b * width * height, out + a + (size_t)b * width * height, height, width, takeSqrt, z, v);
+        free(z); free(v);
+    }
 }
 
 void orc_signed_distance_transform_3d(float *in, float *out, int width, int height, int depth, int takeSqrt) {
@@ -714,34 +781,54 @@ int orc_ne_mod2obs(const float *pred, int width, int height, int modelNum, const
     const int fullDims = 6 + m->n_joints;
     const int dims = reduction ? redDims : fullDims;
     sys_acc s = sys_new(dims);
-    float *de = (float *)malloc(sizeof(float) * (size_t)(fullDims + dims));
-    float *Jr = de + fullDims;
     int numPredictions = 0;
     const int oldcat = stat_enter(ORC_STAT_NE_MOD2OBS);
-    for (int index = 0; index < width * height; ++index) {
-        const float *pc = pred + 4 * index;
-        if (pc[2] == 0) continue;
-        float pm[4], pg[3];
-        se3_apply3(T_gc, pc, pm); pm[3] = 1;
-        orc_grid_coords(obsSdf, pm, pg);
-        if (!orc_grid_in_bounds_gradient_interp(obsSdf, pg)) continue;
-        const float residual = orc_grid_value_interp(obsSdf, pg) * obsSdf->resolution;
-        if (truncationDist >= 0 && (residual >= truncationDist || residual < 0)) continue;
-        const int label = (int)round(pc[3]);
-        const int model = label >> 16;
-        const int sdf = label & 65535;
-        if (model != modelNum) continue;
-        const int predFrame = m->sdf_frame[sdf];
-        float gm[3];
-        orc_grid_gradient_interp(obsSdf, pg, gm);
-        orc_error_jacobian(m, T_fm, T_mf, pm, predFrame, gm, 0, de);
-        const float *J = de;
-        if (reduction) { reduce_jacobian(reduction, 6, fullDims, redDims, de, dtheta_dalpha, mapping, Jr); J = Jr; }
-        ++numPredictions;
-        sys_add_squared(&s, residual, J);
+    const int nT = g_threads > 1 ? g_threads : 1;
+    const int nSys = dims + jtj_size(dims) + 1;
+    const int nPix = width * height;
+    double *part = nT > 1 ? (double *)calloc((size_t)nT * nSys, sizeof(double)) : NULL;
+#pragma omp parallel num_threads(nT) if (nT > 1) reduction(+ : numPredictions)
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        stat_enter(ORC_STAT_NE_MOD2OBS);
+        sys_acc st = s;
+        if (nT > 1) st.acc = part + (size_t)tid * nSys;
+        float *de = (float *)malloc(sizeof(float) * (size_t)(fullDims + dims));
+        float *Jr = de + fullDims;
+        /* interleaved blocks of rows so that the threads share the (compact) silhouette evenly; per thread in pixel order */
+        for (int index = 0; index < nPix; ++index) {
+            if (nT > 1 && ((index / (width > 0 ? width : 1)) % nT) != tid) continue;
+            const float *pc = pred + 4 * index;
+            if (pc[2] == 0) continue;
+            float pm[4], pg[3];
+            se3_apply3(T_gc, pc, pm); pm[3] = 1;
+            orc_grid_coords(obsSdf, pm, pg);
+            if (!orc_grid_in_bounds_gradient_interp(obsSdf, pg)) continue;
+            const float residual = orc_grid_value_interp(obsSdf, pg) * obsSdf->resolution;
+            if (truncationDist >= 0 && (residual >= truncationDist || residual < 0)) continue;
+            const int label = (int)round(pc[3]);
+            const int model = label >> 16;
+            const int sdf = label & 65535;
+            if (model != modelNum) continue;
+            const int predFrame = m->sdf_frame[sdf];
+            float gm[3];
+            orc_grid_gradient_interp(obsSdf, pg, gm);
+            orc_error_jacobian(m, T_fm, T_mf, pm, predFrame, gm, 0, de);
+            const float *J = de;
+            if (reduction) { reduce_jacobian(reduction, 6, fullDims, redDims, de, dtheta_dalpha, mapping, Jr); J = Jr; }
+            ++numPredictions;
+            sys_add_squared(&st, residual, J);
+        }
+        free(de);
+    }
+    if (part) {
+        for (int t = 0; t < nT; ++t) for (int i = 0; i < nSys; ++i) s.acc[i] += part[(size_t)t * nSys + i];
+        free(part);
     }
     stat_enter(oldcat);
-    free(de);
     sys_emit(&s, result);
     return numPredictions;
 }

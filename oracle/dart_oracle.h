@@ -58,6 +58,9 @@ typedef struct { int32_t index; int32_t dataAssociation; float error; } orc_da_p
 /* ---- lookup statistics (measurement aid: number of trilinear lookups per caller category) ---- */
 enum { ORC_STAT_OTHER = 0, ORC_STAT_ASSOC = 1, ORC_STAT_ASSOC_GRAD = 2, ORC_STAT_NE_OBS2MOD = 3, ORC_STAT_RAYCAST = 4,
        ORC_STAT_NE_MOD2OBS = 5, ORC_STAT_INTERSECTION = 6, ORC_STAT_PRIOR = 7, ORC_STAT_CATEGORIES = 8 };
+/* worker threads of the per-pixel loops (OpenMP); 1 = the serial restatement (default, what every parity test uses) */
+void orc_set_threads(int n);
+int orc_get_threads(void);
 void orc_stats_reset(void);
 void orc_stats_enable(int on);
 void orc_stats_get(long long *out /*[ORC_STAT_CATEGORIES]*/);

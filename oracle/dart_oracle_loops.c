@@ -13,6 +13,14 @@
 static int jtj_size(int d) { return (d * (d + 1)) >> 1; }
 static int sys_len(int d) { return d + jtj_size(d) + 1; }
 
+/* Test aid (no reference counterpart): resume a run mid-way. The reference builds the observation SDF (and freezes
+ * T_obsSdf_c) from the pose an optimizePose(s) call STARTS with (optimizer.cpp:446-448, 574-580); to continue a trajectory
+ * from an intermediate pose exactly as the original call would have, the next orc_optimize_pose / orc_optimize_poses call
+ * takes the observation-SDF pose(s) from here ([nModels][12], camera->model) instead of from its own start poses. NULL (the
+ * default) restores the reference behaviour. */
+static const float *g_obsStart = NULL;
+void orc_set_obs_sdf_start(const float *T_mcs) { g_obsStart = T_mcs; }
+
 /* Optimizer::optimizePose, optimizer.cpp:423-522 (NullReduction poses). */
 void orc_optimize_pose(const orc_model *m, float *T_mc, float *joints, const float *vert, const float *norm,
                        int width, int height, const orc_opt_options *o, const float *cloud, int nCloud,
@@ -40,12 +48,13 @@ void orc_optimize_pose(const orc_model *m, float *T_mc, float *joints, const flo
         float T_cm[12];
         const size_t n = (size_t)obs.dim[0] * obs.dim[1] * obs.dim[2];
         float *tmp = (float *)malloc(sizeof(float) * n);
-        orc_se3_invert(T_mc, T_cm);
+        const float *T_start = g_obsStart ? g_obsStart : T_mc;
+        orc_se3_invert(T_start, T_cm);
         orc_splat_obs_sdf(vert, width, height, T_cm, &obs, o->focalLength, obsSdfData);
         orc_distance_transform_3d(obsSdfData, tmp, obs.dim[0], obs.dim[1], obs.dim[2], 1);
         memcpy(obsSdfData, tmp, sizeof(float) * n);
         free(tmp);
-        memcpy(T_obsSdf_c, T_mc, sizeof(float) * 12);
+        memcpy(T_obsSdf_c, T_start, sizeof(float) * 12);
     }
 
     for (int it = 0; it < o->numIterations; ++it) {
@@ -331,12 +340,13 @@ void orc_optimize_poses(const orc_model *const *models, float *const *T_mcs, flo
         for (int m = 0; m < n; ++m) {
             const size_t nv = (size_t)obs[m].dim[0] * obs[m].dim[1] * obs[m].dim[2];
             float *tmp = (float *)malloc(sizeof(float) * nv);
-            orc_se3_invert(T_mcs[m], T_cm[m]);
+            const float *T_start = g_obsStart ? g_obsStart + 12 * m : T_mcs[m];
+            orc_se3_invert(T_start, T_cm[m]);
             orc_splat_obs_sdf(vert, width, height, T_cm[m], &obs[m], o->focalLength, obsSdf[m]);
             orc_distance_transform_3d(obsSdf[m], tmp, obs[m].dim[0], obs[m].dim[1], obs[m].dim[2], 1);
             memcpy(obsSdf[m], tmp, sizeof(float) * nv);
             free(tmp);
-            memcpy(T_obs[m], T_mcs[m], sizeof(float) * 12);
+            memcpy(T_obs[m], T_start, sizeof(float) * 12);
         }
     }
     for (int it = 0; it < o->numIterations; ++it) {

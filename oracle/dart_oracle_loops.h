@@ -22,6 +22,8 @@ typedef struct {
  * the model's obs-SDF size. iterInfo (optional): 8 floats per iteration {errObsToMod, errModToObs, errIntersection,
  * nAssociated, nPredicted, 0,0,0}. firstSystem (optional): the first iteration's packed systems
  * [obs->mod | mod->obs | self-intersection]. */
+/* test aid: the next optimize_pose(s) calls build their observation SDFs at these poses ([nModels][12]); NULL = own start poses */
+void orc_set_obs_sdf_start(const float *T_mcs);
 void orc_optimize_pose(const orc_model *m, float *T_mc, float *joints, const float *vert, const float *norm,
                        int width, int height, const orc_opt_options *o, const float *cloud, int nCloud,
                        const int32_t *potential, float *obsSdfData, float *iterInfo, float *firstSystem);

@@ -448,3 +448,25 @@ def libc_rand(seed, n):
     out = np.zeros(n, dtype=np.int32)
     lib().orc_libc_rand(C.c_uint(seed), C.c_int(n), i(out))
     return out
+
+
+# ---- test aids -------------------------------------------------------------------------------------------------------------
+def set_threads(n):
+    """Worker threads of the oracle's per-pixel loops (1 = the serial restatement, the default)."""
+    lib().orc_set_threads(int(n))
+
+
+class obs_sdf_start:
+    """with obs_sdf_start(T_mcs): the oracle's optimize_pose(s) calls build their observation SDF(s) at these poses instead of
+    at their own start poses -- lets a test resume a trajectory mid-way exactly as the original call would have continued."""
+
+    def __init__(self, T_mcs):
+        self.buf = c32(np.asarray(T_mcs).reshape(-1, 12)).copy()
+
+    def __enter__(self):
+        lib().orc_set_obs_sdf_start(f(self.buf))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_obs_sdf_start(None)
+        return False

@@ -29,15 +29,55 @@ def setup(width, height, iters, frame=0):
     return sc, tr, vert, norm
 
 
-def run(width, height, iters, frame=0):
+def run(width, height, iters, frame=0, device_loop=False):
     sc, tr, vert, norm = setup(width, height, iters, frame)
-    tr.optimizePoses(vert, norm, debug=True)
+    (tr.optimizePosesDevice if device_loop else tr.optimizePoses)(vert, norm, debug=True)
     oT, oa, oinfo, ofirst = O.optimize_poses(tr, vert.cpu().numpy(), norm.cpu().numpy(), [T for T, _ in sc.init], [a for _, a in sc.init])
-    return sc, tr, oT, oa, oinfo, ofirst
+    return sc, tr, vert, norm, oT, oa, oinfo, ofirst
 
 
-def check(sc, tr, oT, oa, oinfo, ofirst, strict_iters):
+def segmented(sc, tr, vert, norm, iters, device_loop):
+    """tests/trajectory.py for Optimizer::optimizePoses: every segment between count flips held to 1e-3, the oracle restarted
+    from the GPU's poses (observation SDFs kept at the run's start poses)."""
+    from trajectory import segmented_parity
+    v_np, n_np = vert.cpu().numpy(), norm.cpu().numpy()
+    init_T = [T for T, _ in sc.init]
+
+    def gpu_prefix(k):
+        tr.getOptions().numIterations = k
+        for m, (T, a) in enumerate(sc.init):
+            tr.getPose(m).setTransformCameraToModel(T)
+            tr.getPose(m).getReducedArticulation()[:] = a
+        (tr.optimizePosesDevice if device_loop else tr.optimizePoses)(vert, norm, debug=True)
+        pose = [(tr.getPose(m).getTransformCameraToModel().copy(), tr.getPose(m).getReducedArticulation().copy()) for m in range(2)]
+        return pose, tr.iteration_summaries.copy()
+
+    def oracle_from(pose, k0, n):
+        tr.getOptions().numIterations = n
+        with O.obs_sdf_start(init_T):
+            oT, oa, oinfo, _ = O.optimize_poses(tr, v_np, n_np, [p[0] for p in pose], [p[1] for p in pose])
+        return [(oT[m], oa[m]) for m in range(2)], oinfo
+
+    def decisions_equal(g, o):
+        return bool(np.array_equal(g[:, 3:5], o[:, 3:5]))
+
+    def pose_err(a, b):
+        e = 0.0
+        for m in range(2):
+            dt, dr = pose_diff(a[m][0], b[m][0])
+            da = float(np.abs(a[m][1] - b[m][1]).max()) if len(b[m][1]) else 0.0
+            e = max(e, dt, dr, da)
+        return e
+
+    name = "C5 %dx%d %s loop" % (sc.width, sc.height, "device" if device_loop else "host-driven")
+    segs = segmented_parity(name, iters, gpu_prefix, oracle_from, decisions_equal, pose_err, bar=1e-3)
+    tr.getOptions().numIterations = iters
+    return segs
+
+
+def check(sc, tr, vert, norm, oT, oa, oinfo, ofirst, device_loop=False):
     ginfo = tr.iteration_summaries
+    iters = len(ginfo)
     # iteration 0: same association / prediction counts per model, same system
     assert np.array_equal(ginfo[0, :, 3:5], oinfo[0, :, 3:5]), (ginfo[0], oinfo[0])
     assert ginfo[0, 0, 3] > 200 and ginfo[0, 1, 3] > 100 and ginfo[0, 0, 4] > 50
@@ -45,25 +85,15 @@ def check(sc, tr, oT, oa, oinfo, ofirst, strict_iters):
     for sl in (slice(0, D * D), slice(D * D, D * D + D)):
         nref = np.linalg.norm(ofirst[sl].astype(np.float64))
         assert np.linalg.norm(tr.first_system[sl].astype(np.float64) - ofirst[sl]) / nref < 1e-4
-    flipped = np.any(ginfo[:, :, 3:5] != oinfo[:, :, 3:5], axis=(1, 2))
-    first_flip = int(np.argmax(flipped)) if flipped.any() else len(ginfo)
-    print("counts agree for %d of %d iterations" % (first_flip, len(ginfo)))
-    assert first_flip >= strict_iters
     for m in range(2):
-        dt, dr = pose_diff(tr.getPose(m).getTransformCameraToModel(), oT[m])
-        da = float(np.abs(tr.getPose(m).getReducedArticulation() - oa[m]).max()) if len(oa[m]) else 0.0
-        raw = float(np.abs(tr.getPose(m).getTransformCameraToModel() - oT[m]).max())
         moved = float(np.abs(oT[m] - sc.init[m][0]).max())
-        print("model %d: |dt|=%.2e m |dr|=%.2e rad max|dq_red|=%.2e (max|dT| %.2e, moved %.2e from the start)" % (m, dt, dr, da, raw, moved))
         assert moved > 1e-4
-        if first_flip == len(ginfo):
-            assert dt < 1e-3 and dr < 1e-3 and da < 1e-3
-        else:
-            assert dt < 5e-3 and dr < 5e-2 and da < 5e-2
+    # every segment of the trajectory between count flips within 1e-3 (no loosened bar)
+    segmented(sc, tr, vert, norm, iters, device_loop)
 
 
 def test_config5_small_matches_oracle(gpu):
-    check(*run(320, 180, 4), strict_iters=2)
+    check(*run(320, 180, 4))
 
 
 def test_config5_moves_towards_truth_and_respects_reduced_limits(gpu):
@@ -83,7 +113,7 @@ def test_config5_moves_towards_truth_and_respects_reduced_limits(gpu):
 
 def test_config5_full_resolution(gpu):
     """BASELINE config 5 at its full 1280x720: counts and first system against the oracle, 2 iterations."""
-    check(*run(1280, 720, 2), strict_iters=1)
+    check(*run(1280, 720, 2))
 
 
 def test_device_loop_matches_host_driven_loop_and_oracle(gpu):
@@ -106,15 +136,21 @@ def test_device_loop_matches_host_driven_loop_and_oracle(gpu):
     assert np.array_equal(tr.iteration_summaries[0, :, 3:5], host_info[0, :, 3:5])
     assert np.allclose(tr.iteration_summaries[0, :, :3], host_info[0, :, :3], rtol=1e-4, atol=1e-7)
     same_counts = np.array_equal(tr.iteration_summaries[:, :, 3:5], host_info[:, :, 3:5])
+    dev_T = [tr.getPose(m).getTransformCameraToModel().copy() for m in range(2)]
+    dev_a = [tr.getPose(m).getReducedArticulation().copy() for m in range(2)]
     for m in range(2):
-        dt, dr = pose_diff(tr.getPose(m).getTransformCameraToModel(), host_T[m])
-        da = float(np.abs(tr.getPose(m).getReducedArticulation() - host_a[m]).max()) if len(host_a[m]) else 0.0
+        dt, dr = pose_diff(dev_T[m], host_T[m])
+        da = float(np.abs(dev_a[m] - host_a[m]).max()) if len(host_a[m]) else 0.0
         print("model %d device loop vs host loop: |dt|=%.2e |dr|=%.2e max|dq_red|=%.2e (counts equal: %s)" % (m, dt, dr, da, same_counts))
-        bar = 1e-4 if same_counts else 5e-3
-        assert dt < bar and dr < 10 * bar and da < 10 * bar
-    # and the oracle
+        if same_counts:     # same discrete decisions: the two loops are the same arithmetic up to the order of the appended lists
+            assert dt < 1e-4 and dr < 1e-3 and da < 1e-3
+    # and the oracle, segment by segment
     oT, oa, oinfo, ofirst = O.optimize_poses(tr, vert.cpu().numpy(), norm.cpu().numpy(), [T for T, _ in sc.init], [a for _, a in sc.init])
-    check(sc, tr, oT, oa, oinfo, ofirst, strict_iters=1)
+    check(sc, tr, vert, norm, oT, oa, oinfo, ofirst, device_loop=True)
+    for m, (T, a) in enumerate(sc.init):
+        tr.getPose(m).setTransformCameraToModel(T)
+        tr.getPose(m).getReducedArticulation()[:] = a
+    tr.optimizePosesDevice(vert, norm, debug=True)
     # the full joint vector on the device is the projection of the reduced one (Barrett: 8 joints from 4)
     _, _, _, joints = tr.models[0].get_transforms()
     assert np.allclose(joints, tr.getPose(0).getArticulation(), atol=1e-6)
@@ -134,7 +170,10 @@ def test_device_loop_repeats(gpu):
         runs.append(([tr.getPose(m).getTransformCameraToModel().copy() for m in range(2)],
                      tr.getPose(0).getReducedArticulation().copy(), tr.iteration_summaries.copy()))
     for T, a, info in runs[1:]:
-        assert np.array_equal(info[:, :, 3:5], runs[0][2][:, :, 3:5])
+        # iteration 0 starts from identical inputs: exact counts. Later iterations start from poses that agree only to the
+        # rounding of the atomically appended lists, so a pixel sitting on a threshold may flip: a few points of tolerance.
+        assert np.array_equal(info[0, :, 3:5], runs[0][2][0, :, 3:5])
+        assert np.abs(info[:, :, 3:5] - runs[0][2][:, :, 3:5]).max() <= 3
         for m in range(2):
             assert np.abs(T[m] - runs[0][0][m]).max() < 2e-5      # measured 2e-6 on one stream and on three alike
         assert np.abs(a - runs[0][1]).max() < 1e-4                  # measured 1.6e-5

@@ -1,6 +1,7 @@
 """GPU parity: the device-resident Gauss-Newton loop (Optimizer::optimizePose) vs the CPU oracle's restatement
-of optimizer.cpp:423-522. Bars: first-iteration systems within 1e-4 (norm-relative), converged poses within
-1e-3 rad on angles and 1e-3 mm (1e-6 m) ... reported; asserted at 1e-3 rad / 1e-3 m with the achieved value printed."""
+of optimizer.cpp:423-522. Bars: first-iteration systems within 1e-4 (norm-relative); poses within 1e-3 rad / 1e-3 m on every
+segment of the trajectory (tests/trajectory.py: the oracle is restarted from the GPU pose at every discrete-decision flip --
+no loosened bar anywhere), achieved values printed."""
 import numpy as np
 import pytest
 import torch
@@ -42,6 +43,44 @@ def pose_diff(Ta, Tb):
     return float(np.linalg.norm(D_[:3, 3])), float(ang)
 
 
+def segmented_pose_parity(sc0, cfg, size, gpu, iters, lam_m2o=1.0):
+    """tests/trajectory.py for Optimizer::optimizePose: GPU prefixes from the common start vs the oracle restarted from the
+    GPU's pose at every decision flip (observation SDF kept at the run's start pose, as the original call has it)."""
+    from trajectory import segmented_parity
+    sc = cfg(*size)
+    m = sc.host_model
+    om = O.OModel(m, 0, sc.obs_layout)
+    dm = D.DeviceModel(m, model_id=0, obs_layout=sc.obs_layout)
+    dm.set_pose(sc.true_T_mc, sc.true_joints)
+    _, vert, norm = synthetic_observation([dm], sc.width, sc.height, sc.fl, sc.pp)
+    v_np, n_np = vert.cpu().numpy(), norm.cpu().numpy()
+    sc.opts.lambdaModToObs = lam_m2o
+    opt = Optimizer(sc.width, sc.height, sc.fl, sc.pred_width, sc.pred_height)
+
+    def gpu_prefix(k):
+        sc.opts.numIterations = k
+        dm.set_pose(sc.init_T_mc, sc.init_joints)
+        opt.optimizePose(dm, vert, norm, sc.opts, debug=True)
+        T, _, _, j = dm.get_transforms()
+        return (T.copy(), j.copy()), opt.iter_info.cpu().numpy().copy()
+
+    def oracle_from(pose, k0, n):
+        sc.opts.numIterations = n
+        o_struct = sc.opts.c_struct(0, opt.pred_width, opt.pred_height, opt.pred_fl)
+        with O.obs_sdf_start(sc.init_T_mc):
+            T, j, info, _ = O.optimize_pose(om, pose[0], pose[1], v_np, n_np, o_struct)
+        return (T, j), info
+
+    def decisions_equal(g, o):
+        return bool(np.all(g[3:5] == o[3:5]) and np.all(np.abs(g[0:2] - o[0:2]) <= 2e-5 * np.abs(o[0:2]) + 1e-9))
+
+    def pose_err(a, b):
+        dt, dr = pose_diff(a[0], b[0])
+        return max(dt, dr, float(np.abs(a[1] - b[1]).max()) if len(a[1]) else 0.0)
+
+    return segmented_parity(sc.name, iters, gpu_prefix, oracle_from, decisions_equal, pose_err, bar=1e-3)
+
+
 @pytest.mark.parametrize("cfg,size", [(configs.config1, (320, 240)), (configs.config2, (320, 240)), (configs.config2_left_hand, (320, 240))])
 def test_optimize_pose_matches_oracle(gpu, cfg, size):
     sc = cfg(*size)
@@ -53,29 +92,13 @@ def test_optimize_pose_matches_oracle(gpu, cfg, size):
     assert g_info[0, 4] == o_info[0, 4] and g_info[0, 4] > 200
     assert rel_err_blocks(g_first[:S], o_first[:S], dims) < 1e-4
     assert rel_err_blocks(g_first[S:2 * S], o_first[S:2 * S], dims) < 1e-4
-    # converged pose. The partial sums are added in a different order than the oracle's, so the systems agree to
-    # ~1e-7 relative, not bitwise; as long as every discrete decision (association / prediction counts) is the same
-    # on both sides the poses stay within the 1e-3 bar. When a borderline pixel flips in a late iteration (a
-    # "documented near-tie") the two trajectories legitimately separate on weakly observed joints: then the
-    # strict bar is applied to the last iteration before the flip (re-run below) and a loose one to the end pose.
+    # converged pose: every segment of the trajectory between discrete-decision flips is held to 1e-3 (tests/trajectory.py)
     dt, dr = pose_diff(g_T, o_T)
     dj = float(np.abs(g_j - o_j).max()) if len(g_j) else 0.0
-    print("pose parity %s: |dt|=%.3e m |dr|=%.3e rad max|dq|=%.3e rad" % (sc.name, dt, dr, dj))
-    flipped = np.any(g_info[:, 3:5] != o_info[:, 3:5], axis=1) | \
-        np.any(np.abs(g_info[:, 0:2] - o_info[:, 0:2]) > 2e-5 * np.abs(o_info[:, 0:2]) + 1e-9, axis=1)
-    if not flipped.any():
+    print("free-running pose parity %s: |dt|=%.3e m |dr|=%.3e rad max|dq|=%.3e rad" % (sc.name, dt, dr, dj))
+    segs = segmented_pose_parity(sc, cfg, size, gpu, 5)
+    if len(segs) == 1:
         assert dt < 1e-3 and dr < 1e-3 and dj < 1e-3
-    else:
-        first_flip = int(np.argmax(flipped))
-        print("near-tie flip at iteration %d: counts gpu %s oracle %s" % (first_flip, g_info[first_flip, 3:5], o_info[first_flip, 3:5]))
-        assert first_flip >= 2 and np.abs(g_info[first_flip, 3:5] - o_info[first_flip, 3:5]).max() <= 2
-        assert dt < 5e-3 and dr < 5e-2 and dj < 5e-2
-        sc2 = cfg(*size)
-        _, g_T2, g_j2, g_i2, _, o_T2, o_j2, o_i2, _ = run_scene(sc2, gpu, iters=first_flip)
-        dt2, dr2 = pose_diff(g_T2, o_T2)
-        dj2 = float(np.abs(g_j2 - o_j2).max()) if len(g_j2) else 0.0
-        print("pose parity before the flip (%d iterations): |dt|=%.3e |dr|=%.3e max|dq|=%.3e" % (first_flip, dt2, dr2, dj2))
-        assert dt2 < 1e-3 and dr2 < 1e-3 and dj2 < 1e-3
     # and the optimisation actually did its job: the translation error and the total energy went down
     # (rotation is unobservable for the sphere and weakly observable for proxy hands in 5 damped iterations)
     t0, _ = pose_diff(sc.init_T_mc, sc.true_T_mc)
