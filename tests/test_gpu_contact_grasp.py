@@ -84,24 +84,21 @@ def test_get_error_matches_oracle(gpu):
     assert abs(tr.getError() - e[3]) < 1e-6
 
 
-def test_full_refinement_40_iterations(gpu):
-    """BASELINE config 3: 40 iterations (grasp_analyzer.cpp:198). Every segment of the trajectory between decision flips
-    (a contact prior crossing its threshold / cylinder gate, a collision point entering or leaving an SDF) is held to 1e-3
-    (tests/trajectory.py: the oracle is restarted from the GPU's poses at every flip); the energy must stay finite."""
+def segmented_grasp(name, sc, tr, T1, j1, iters):
+    """tests/trajectory.py for one grasp candidate (T1 [2,12], j1 [nJ]): GPU prefixes (batch of one) vs the oracle restarted
+    from the GPU's poses at every decision flip. Returns (segments, gpu end pose, gpu energy, oracle energy of the last segment)."""
     from trajectory import segmented_parity
-    sc = scene(4)
-    tr = configs.make_grasp_tracker(sc)
-    T, j = configs.grasp_batch_arrays(sc)
     oms = [O.OModel(sc.hand, 0), O.OModel(sc.obj, 1)]
     clouds = [c.cpu().numpy() for c in tr.clouds]
     pots = [p.cpu().numpy() for p in tr.potentials]
-    energies = {}
+    energies, poses = {}, {}
 
     def gpu_prefix(k):
         tr.getOptions().numIterations = k
-        gT, gj, ge, ginfo, _ = tr.optimizePosesBatch(T[:1], j[:1], debug=True)
+        gT, gj, ge, ginfo, _ = tr.optimizePosesBatch(T1[None], j1[None], debug=True)
         energies[k] = float(ge[0])
-        return (gT[0, 0].copy(), gT[0, 1].copy(), gj[0].copy()), ginfo[0].copy()
+        poses[k] = (gT[0, 0].copy(), gT[0, 1].copy(), gj[0].copy())
+        return poses[k], ginfo[0].copy()
 
     def oracle_from(pose, k0, n):
         tr.getOptions().numIterations = n
@@ -119,8 +116,19 @@ def test_full_refinement_40_iterations(gpu):
         dto, dro = pose_diff(a[1], b[1])
         return max(dt, dr, dto, dro, float(np.abs(a[2] - b[2]).max()))
 
-    segs = segmented_parity("C3 ContactGrasp 40 iterations", 40, gpu_prefix, oracle_from, decisions_equal, pose_err, bar=1e-3)
-    ge, oe = energies[40], energies[("oracle", 40)]
+    segs = segmented_parity(name, iters, gpu_prefix, oracle_from, decisions_equal, pose_err, bar=1e-3)
+    tr.getOptions().numIterations = iters
+    return segs, poses[iters], energies[iters], energies[("oracle", iters)]
+
+
+def test_full_refinement_40_iterations(gpu):
+    """BASELINE config 3: 40 iterations (grasp_analyzer.cpp:198). Every segment of the trajectory between decision flips
+    (a contact prior crossing its threshold / cylinder gate, a collision point entering or leaving an SDF) is held to 1e-3
+    (tests/trajectory.py: the oracle is restarted from the GPU's poses at every flip)."""
+    sc = scene(4)
+    tr = configs.make_grasp_tracker(sc)
+    T, j = configs.grasp_batch_arrays(sc)
+    segs, _, ge, oe = segmented_grasp("C3 ContactGrasp 40 iterations", sc, tr, T[0], j[0], 40)
     print("energy after 40 iterations: gpu %.6f, oracle (last segment) %.6f" % (ge, oe))
     assert abs(ge - oe) < 1e-3 * max(1.0, abs(oe))
     assert segs[0][1] >= 10, "the first decision flip came at iteration %d" % segs[0][1]
@@ -185,7 +193,7 @@ def test_full_size_batch_properties(gpu):
     T, j = T.copy(), j.copy()
     T[n - 7], j[n - 7] = T[11], j[11]           # duplicates far apart in the batch (different workgroups, different XCDs)
     T[2048], j[2048] = T[11], j[11]
-    iters = 3
+    iters = 40                                  # the configuration's own iteration count (grasp_analyzer.cpp:198)
     tr.getOptions().numIterations = iters
     gT, gj, ge, _, _ = tr.optimizePosesBatch(T, j)
     assert np.isfinite(gT).all() and np.isfinite(gj).all() and np.isfinite(ge).all()
@@ -193,13 +201,17 @@ def test_full_size_batch_properties(gpu):
         assert np.array_equal(gT[c], gT[11]) and np.array_equal(gj[c], gj[11]) and ge[c] == ge[11]
     rT, rj, re_, _, _ = tr.optimizePosesBatch(T[::-1].copy(), j[::-1].copy())
     assert np.array_equal(rT[::-1], gT) and np.array_equal(rj[::-1], gj) and np.array_equal(re_[::-1], ge)
-    for c in (0, 11, 1500, 3333, n - 1):
-        oT, oj, oe, _, _ = oracle_run(sc, tr, T[c, 0], j[c], iters)
-        dt, dr = pose_diff(gT[c, 0], oT[0])
-        dj = float(np.abs(gj[c] - oj[0]).max())
-        print("candidate %4d of %d: |dt|=%.2e |dr|=%.2e max|dq|=%.2e energy gpu %.6f oracle %.6f" % (c, n, dt, dr, dj, ge[c], oe))
-        assert dt < 1e-3 and dr < 1e-3 and dj < 1e-3
-        assert abs(ge[c] - oe) < 1e-3 * max(1.0, abs(oe))
+    # a sample of candidates over all 40 iterations: the candidate alone (batch of one: other workgroup split, other fixed
+    # summation order) against the oracle segment by segment, and the batch's result against the candidate alone
+    tr1 = configs.make_grasp_tracker(sc, max_batch=1)
+    for c in (0, 11, 777, 1500, 2600, 3333, n - 1):
+        segs, pose1, e1, oe = segmented_grasp("C4 candidate %d of %d" % (c, n), sc, tr1, T[c], j[c], iters)
+        dt, dr = pose_diff(gT[c, 0], pose1[0])
+        dto, dro = pose_diff(gT[c, 1], pose1[1])
+        dj = float(np.abs(gj[c] - pose1[2]).max())
+        print("candidate %4d: batch vs alone |dt|=%.2e |dr|=%.2e max|dq|=%.2e; energy batch %.6f alone %.6f oracle %.6f" % (c, dt, dr, dj, ge[c], e1, oe))
+        assert max(dt, dr, dto, dro, dj) < 1e-3
+        assert abs(e1 - oe) < 1e-3 * max(1.0, abs(oe)) and abs(ge[c] - e1) < 1e-3 * max(1.0, abs(e1))
     e2 = tr.getError(gT, gj)
     assert np.allclose(e2, ge, rtol=1e-6, atol=1e-7)
     # the refinement lowers the mean energy of the batch

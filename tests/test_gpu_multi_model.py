@@ -112,8 +112,10 @@ def test_config5_moves_towards_truth_and_respects_reduced_limits(gpu):
 
 
 def test_config5_full_resolution(gpu):
-    """BASELINE config 5 at its full 1280x720: counts and first system against the oracle, 2 iterations."""
-    check(*run(1280, 720, 2))
+    """BASELINE config 5 at its full 1280x720: counts and first system against the oracle, all 5 iterations of the
+    configuration segment by segment, host-driven and device-resident loops."""
+    check(*run(1280, 720, 5))
+    check(*run(1280, 720, 5, device_loop=True), device_loop=True)
 
 
 def test_device_loop_matches_host_driven_loop_and_oracle(gpu):
