@@ -13,9 +13,14 @@ whole job. One frame is never split across GPUs (north_star): with N ranks every
 Extra objects on the same JSON line:
   roofline        the dominant kernel of the headline path: ALGORITHMIC bytes per launch / its average launch duration,
                   measured with HIP events on the launch stream in a second pass over the same K steps (events add
-                  overhead, so the throughput pass runs without them); peak = 8 TB/s HBM (MI355X_MICROARCH.md);
-                  `traffic` = PMC HBM bytes per launch when profiles/ holds them for this kernel, else null.
-  cpu_baseline    the CPU oracle (plain C restatement, "port") timed on this host on a bounded sample, 1 thread.
+                  overhead, so the throughput pass runs without them); peak = 8 TB/s HBM (MI355X_MICROARCH.md). The
+                  algorithmic bytes price the work the kernel PERFORMS: its trilinear lookups are counted on the device by the
+                  diagnostic twin of the library (libdartk_count.so, dartk_lookup_counters) on the same inputs -- not the
+                  lookups the reference's un-pruned loops would make. `traffic` = PMC HBM bytes per launch (profiles/),
+                  `frac_hbm` = traffic / duration / peak, `l2_gather_GBs` = 32 B x lookups / duration.
+  cpu_baseline    the CPU oracle (plain C restatement, "port") timed on this host on a bounded sample with all of this
+                  process's cores (OpenMP / threads; `cores` says how many) and, nested, with one thread; CPU model printed.
+  repeats         the timed K-step loop repeated (default 24 more times): median / min / max ms per step.
   batched_grasps  BASELINE config 4: 4096 HumanHand grasp candidates x 40 iterations of OptimizerNoObs (contact priors
                   + intersection terms), candidates sharded round-robin over the N ranks (strong scaling for this leg),
                   one all-gather of {energy, pose}; grasps/s, its own roofline and CPU baseline.
@@ -34,6 +39,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0
+TRACE_BYTES_PER_PAIR = 8        # ray-cast trace record per (prediction pixel, SDF): {detection t, hit t}
 PROF_NAMES = ["obs_sdf_build", "raycast_trace_kernel", "fused_obs2mod_kernel", "ne_mod2obs_kernel", "ne_self_intersection_kernel",
               "gn_solve_single_kernel", "raycast_replay_kernel", "valid_pixel_compaction", "gn_reduce_kernel",
               "noobs_terms_kernel<intersection>", "noobs_solve_kernel", "noobs_terms_kernel<priors>"]
@@ -58,6 +64,50 @@ def prof_collect(lib, fptr, iptr, check, fn, reps):
     per_launch_us = {PROF_NAMES[i]: float(1000.0 * ms[i] / cnt[i]) for i in range(N_CLASSES) if cnt[i]}
     per_step_us = {PROF_NAMES[i]: float(1000.0 * ms[i] / reps) for i in range(N_CLASSES) if cnt[i]}
     return per_launch_us, per_step_us
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_threads(args):
+    if args.cpu_threads > 0:
+        return args.cpu_threads
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    return int(env) if env.isdigit() and int(env) > 0 else min(os.cpu_count() or 1, 16)
+
+
+def count_lookups(fn):
+    """Run fn() through libdartk_count.so (the diagnostic build with one counter per trilinear lookup) and return the
+    counts by category [other, assoc, assoc gradient, obs->mod gradient, ray-cast, mod->obs, intersection, priors]."""
+    from dart_amd import _abi
+    cnt = (C.c_uint64 * 8)()
+    with _abi.counting_library() as L:
+        _abi.check(L.dartk_lookup_counters(cnt, 1))
+        fn()
+        _abi.check(L.dartk_lookup_counters(cnt, 1))
+    return [int(v) for v in cnt]
+
+
+def roofline_entry(name, bytes_per_launch, lookups_per_launch, per_launch_us):
+    """One kernel's roofline figures. achieved = algorithmic bytes of the work performed / measured duration."""
+    us = per_launch_us[name]
+    ach = bytes_per_launch / (us * 1e-6) / 1e9
+    traffic = PMC_TRAFFIC.get(name)
+    e = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+         "frac_hbm": round(traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
+         "l2_gather_GBs": round(32.0 * lookups_per_launch / (us * 1e-6) / 1e9, 2),
+         "algorithmic_bytes_per_launch": round(bytes_per_launch), "lookups_per_launch": round(lookups_per_launch),
+         "avg_launch_us": round(us, 2)}
+    assert e["frac"] <= 1.0, "a roofline fraction above 1 means the priced work is not the work performed: %r" % e
+    return e
 
 
 def tr_slab_floats(tr):
@@ -90,6 +140,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=24, help="further repeats of the timed K-step loop for the median / min / max line")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline (0 = OMP_NUM_THREADS or min(cpu_count, 16))")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--norm-threshold", type=float, default=None, help="override the workload's normal gate (reference default -0.1)")
     ap.add_argument("--grasp-candidates", type=int, default=4096)
@@ -178,64 +230,87 @@ def main():
         out = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(out, rec)
 
+    # repeats of the timed loop (same K steps): spread of the measurement, local to this rank
+    rep = []
+    for _ in range(0 if args.no_tracking else args.repeats):
+        torch.cuda.synchronize()
+        tr0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+        rep.append(1000.0 * (time.perf_counter() - tr0) / max(n_steps, 1))
+    repeats = None
+    if rep:
+        rep_all = sorted(rep + [1000.0 * elapsed / max(n_steps, 1)])
+        repeats = {"n": len(rep_all), "ms_per_step_median": round(float(np.median(rep_all)), 4), "ms_per_step_min": round(rep_all[0], 4),
+                   "ms_per_step_max": round(rep_all[-1], 4), "value_median": round(world * iters / (float(np.median(rep_all)) * 1e-3), 1)}
+
     roofline = None
     cpu_baseline = None
     if rank == 0 and not args.no_tracking:
         import oracle_lib as O
         per_launch_us, per_step_us = prof_collect(lib(), fptr, iptr, check, step, args.steps)
-        # algorithmic bytes from exact counts of one step of the CPU oracle on this workload
+        # lookups the kernels perform in one step (device counters of the diagnostic library, same inputs, same poses)
+        cnt = count_lookups(lambda: step(debug=True))
         om = O.OModel(sc.host_model, 0, sc.obs_layout)
         o_struct = sc.opts.c_struct(0, opt.pred_width, opt.pred_height, opt.pred_fl)
         v_np, n_np = vert.cpu().numpy(), norm.cpu().numpy()
-        O.lib().orc_stats_reset()
-        O.lib().orc_stats_enable(1)
-        _, _, o_info, _ = O.optimize_pose(om, sc.init_T_mc, sc.init_joints, v_np, n_np, o_struct)
-        O.lib().orc_stats_enable(0)
-        st = (C.c_longlong * 8)()
-        O.lib().orc_stats_get(st)
+        info_np = opt.iter_info.cpu().numpy()
         P = opt.pred_width * opt.pred_height
         S = 22 + 22 * 23 // 2 + 1
         n_valid = int((v_np[..., 3] > 0).sum())
-        n_assoc = float(o_info[:, 3].mean())
-        n_pred = float(o_info[:, 4].mean())
+        n_assoc = float(info_np[:, 3].mean())
+        n_pred = float(info_np[:, 4].mean())
         n_sdfs = len(sc.host_model.sdfs)
+        lk = {"fused_obs2mod_kernel": (cnt[1] + cnt[2]) / iters, "raycast_trace_kernel": cnt[4] / iters, "ne_mod2obs_kernel": cnt[5] / iters}
+        trace_bytes = float(TRACE_BYTES_PER_PAIR) * P * n_sdfs
         bytes_per_launch = {
-            # 4 B index + 16 B vertex per valid pixel + 32 B per trilinear lookup of the association scan + (16 B normal +
-            # 192 B gradient) per associated candidate + one partial system per workgroup
-            "fused_obs2mod_kernel": 20.0 * n_valid + 32.0 * st[O_ASSOC] / iters + 16.0 * st[O_ASSOC_GRAD] / 6 / iters
-                                    + 32.0 * st[O_ASSOC_GRAD] / iters + 4.0 * S * ((n_valid + 127) // 128),
-            # 32 B per marching-step lookup (the reference's pruned count) + 8 B trace record per (pixel, SDF)
-            "raycast_trace_kernel": 32.0 * st[O_RAYCAST] / iters + 8.0 * P * n_sdfs,
-            # (the replay of the traces is part of this kernel) 8 B trace record per (pixel, SDF) + prediction read and
+            # 4 B index + 16 B vertex per valid pixel + 32 B per trilinear lookup performed (association scan of the SDFs
+            # whose keep box holds the point + the 6-lookup gradient of the associated ones) + 16 B normal per candidate
+            # + one partial system per workgroup
+            "fused_obs2mod_kernel": 20.0 * n_valid + 32.0 * lk["fused_obs2mod_kernel"] + 16.0 * cnt[2] / 6 / iters
+                                    + 4.0 * S * ((n_valid + 127) // 128),
+            # 32 B per marching-step lookup performed + the trace records written for the replay
+            "raycast_trace_kernel": 32.0 * lk["raycast_trace_kernel"] + trace_bytes,
+            # (the replay of the traces is part of this kernel) trace records read + prediction read and
             # write + 32 B per lookup (value + gradient) + one partial system per 128-pixel tile
-            "ne_mod2obs_kernel": 8.0 * P * n_sdfs + 32.0 * P + 32.0 * st[O_M2O] / iters + 4.0 * S * min((P + 127) // 128, 1024),
+            "ne_mod2obs_kernel": trace_bytes + 32.0 * P + 32.0 * lk["ne_mod2obs_kernel"] + 4.0 * S * min((P + 127) // 128, 1024),
             "gn_reduce_kernel": 4.0 * S * (min((P + 127) // 128, 1024) + (n_valid + 127) // 128) + 8.0 * S,
             "gn_solve_single_kernel": 4.0 * 2 * S + 96.0 * 17 * 2,
             "obs_sdf_build": 4.0 * 64 ** 3 * 9 + 16.0 * 64 ** 3,
         }
         cands = {k: v for k, v in per_step_us.items() if k in bytes_per_launch}
         name = max(cands, key=cands.get)
-        ach = bytes_per_launch[name] / (per_launch_us[name] * 1e-6) / 1e9
-        roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": PMC_TRAFFIC.get(name),
-                    "algorithmic_bytes_per_launch": round(bytes_per_launch[name]),
-                    "avg_launch_us": round(per_launch_us[name], 2),
-                    "per_step_us": {k: round(v, 2) for k, v in per_step_us.items()},
-                    "per_kernel_achieved_GBs": {k: round(bytes_per_launch[k] / (per_launch_us[k] * 1e-6) / 1e9, 2)
-                                                for k in bytes_per_launch if k in per_launch_us},
-                    "counts": {"valid_pixels": n_valid, "associated_per_iter": n_assoc, "predicted_per_iter": n_pred,
-                               "assoc_lookups_per_iter": st[O_ASSOC] / iters, "raycast_lookups_per_iter": st[O_RAYCAST] / iters},
-                    "note": "latency-bound at batch 1: one frame's working set (~35 MB/iteration, SDFs L2/MALL-resident) cannot "
-                            "approach the HBM roof; the obs->mod chain and the ray-cast + mod->obs chain overlap on two streams, "
-                            "so per_step_us sums exceed ms_per_step"}
+        roofline = roofline_entry(name, bytes_per_launch[name], lk.get(name, 0.0), per_launch_us)
+        it_bytes = sum(bytes_per_launch[k] for k in ("fused_obs2mod_kernel", "raycast_trace_kernel", "ne_mod2obs_kernel", "gn_reduce_kernel",
+                                                     "gn_solve_single_kernel"))
+        roofline.update({
+            "per_step_us": {k: round(v, 2) for k, v in per_step_us.items()},
+            "per_kernel": {k: roofline_entry(k, bytes_per_launch[k], lk.get(k, 0.0), per_launch_us) for k in bytes_per_launch if k in per_launch_us},
+            "whole_iteration": {"algorithmic_bytes": round(it_bytes), "achieved_GBs": round(it_bytes / (elapsed / max(n_steps * iters, 1)) / 1e9, 2),
+                                "frac": round(it_bytes / (elapsed / max(n_steps * iters, 1)) / 1e9 / HBM_PEAK_GBS, 5)},
+            "counts": {"valid_pixels": n_valid, "associated_per_iter": n_assoc, "predicted_per_iter": n_pred,
+                       "lookups_performed_per_iter": {"association_scan": cnt[1] / iters, "association_gradient": cnt[2] / iters,
+                                                      "raycast_march": cnt[4] / iters, "mod2obs": cnt[5] / iters}},
+            "note": "latency-bound at batch 1: one frame's working set (SDFs L2/MALL-resident) cannot approach the HBM roof; the "
+                    "obs->mod chain and the ray-cast + mod->obs chain overlap on two streams, so per_step_us sums exceed ms_per_step"})
         if not args.no_cpu_baseline:
-            tc0 = time.perf_counter()
-            for _ in range(args.cpu_steps):
-                O.optimize_pose(om, sc.init_T_mc, sc.init_joints, v_np, n_np, o_struct)
-            cpu_t = time.perf_counter() - tc0
-            cpu_baseline = {"value": round(args.cpu_steps * iters / cpu_t, 3), "unit": "GN iterations/s", "cores": 1, "kind": "port",
-                            "sample": "%d whole steps (obs-SDF build + %d iterations) of the same 640x480 Allegro workload, CPU oracle, 1 thread"
-                                      % (args.cpu_steps, iters)}
+            nthr = cpu_threads(args)
+
+            def time_cpu(threads, n):
+                O.set_threads(threads)
+                tc0 = time.perf_counter()
+                for _ in range(n):
+                    O.optimize_pose(om, sc.init_T_mc, sc.init_joints, v_np, n_np, o_struct)
+                dt_ = time.perf_counter() - tc0
+                O.set_threads(1)
+                return n * iters / dt_
+            one = time_cpu(1, args.cpu_steps)
+            many = time_cpu(nthr, max(args.cpu_steps, 2 * nthr // 4))
+            sample = "whole steps (obs-SDF build + %d iterations) of the same 640x480 Allegro workload, CPU oracle (OpenMP over pixels / rays)" % iters
+            cpu_baseline = {"value": round(many, 3), "unit": "GN iterations/s", "cores": nthr, "kind": "port", "cpu_model": cpu_model_name(),
+                            "sample": "%d %s, %d threads" % (max(args.cpu_steps, 2 * nthr // 4), sample, nthr),
+                            "single_thread": {"value": round(one, 3), "cores": 1, "sample": "%d %s, 1 thread" % (args.cpu_steps, sample)}}
 
     # ================================================================== BASELINE config 4: batched ContactGrasp refinement
     grasps = None
@@ -268,47 +343,67 @@ def main():
             import oracle_lib as O
             best = sharding.best_candidates(full_e, 5)
             per_launch_us, per_step_us = prof_collect(lib(), fptr, iptr, check, grefine, 1)
-            # algorithmic bytes of one terms-kernel launch (contact priors + intersection) from oracle counts on a
-            # sample of this rank's candidates at their initial poses
+            # algorithmic bytes of one terms-kernel launch (contact priors + intersection) with the lookups the kernels
+            # perform, counted by the diagnostic library on a sample of this rank's candidates (2 iterations + getError = 3
+            # passes of every term kernel per candidate)
             oms = [O.OModel(gs.hand, 0), O.OModel(gs.obj, 1)]
-            o = tr._options_struct()
             clouds = [c.cpu().numpy() for c in tr.clouds]
             pots = [p.cpu().numpy() for p in tr.potentials]
-            sample = list(range(0, len(idx), max(1, len(idx) // 8)))[:8]
-            O.lib().orc_stats_reset()
-            O.lib().orc_stats_enable(1)
-            for c in sample:
-                O.get_error_noobs(oms, [T_all[idx[c], 0], T_all[idx[c], 1]], [j_all[idx[c]], np.zeros(0, dtype=np.float32)], o, clouds, pots, gs.priors)
-            O.lib().orc_stats_enable(0)
-            st = (C.c_longlong * 8)()
-            O.lib().orc_stats_get(st)
-            lk_inter, lk_prior = st[O_INTER] / len(sample), st[O_PRIOR] / len(sample)
+            n_cs = min(len(idx), 512)
+            from dart_amd import _abi
+
+            def counted():
+                trc = configs.make_grasp_tracker(gs, max_batch=n_cs)
+                trc.getOptions().numIterations = 2
+                trc.optimizePosesBatch(Td[:n_cs].clone(), jd[:n_cs].clone(), device_arrays=True)
+                torch.cuda.synchronize()
+            cnt = count_lookups(counted)
+            lk_inter, lk_prior = cnt[6] / (3.0 * n_cs), cnt[7] / (3.0 * n_cs)
             Q = len(gs.priors)
             Cn = sum(len(c) for c in clouds) + len(clouds[0])      # the hand cloud is walked twice (self + object)
             slab_inter, slab_prior = tr_slab_floats(tr)
             K_I, K_P = "noobs_terms_kernel<intersection>", "noobs_terms_kernel<priors>"
-            # per candidate and pass: 40 B per contact prior / 16 B per cloud point + 32 B per trilinear lookup + partial systems
-            bytes_per_launch = {K_P: (40.0 * Q + 32.0 * lk_prior + 4.0 * slab_prior) * len(idx),
+            # per candidate and pass: 40 B per contact prior / 16 B per cloud point + 32 B per trilinear lookup performed + partial
+            # systems + the candidate's pose record (transforms of both models, read by every workgroup)
+            pose_bytes = 4.0 * sum(24 + max(m.n_joints, 1) + 24 * m.n_frames for m in (gs.hand, gs.obj))
+            bytes_per_launch = {K_P: (40.0 * Q + 32.0 * lk_prior + 4.0 * slab_prior + pose_bytes) * len(idx),
                                 # three intersection kernels per pass: the figure is their sum over the class's launches
-                                K_I: (16.0 * Cn + 32.0 * lk_inter + 4.0 * slab_inter) * len(idx) / 3.0}
+                                K_I: (16.0 * Cn + 32.0 * lk_inter + 4.0 * slab_inter + 3 * pose_bytes) * len(idx) / 3.0}
+            lk_launch = {K_P: lk_prior * len(idx), K_I: lk_inter * len(idx) / 3.0}
             g_name = max((K_I, K_P), key=lambda k: per_step_us.get(k, 0.0))
-            bpl = bytes_per_launch[g_name]
-            us = per_launch_us[g_name]
-            ach = bpl / (us * 1e-6) / 1e9
+            g_roof = roofline_entry(g_name, bytes_per_launch[g_name], lk_launch[g_name], per_launch_us)
+            g_roof.update({"per_step_us": {k: round(v, 2) for k, v in per_step_us.items()},
+                           "per_kernel": {k: roofline_entry(k, bytes_per_launch[k], lk_launch[k], per_launch_us) for k in bytes_per_launch if k in per_launch_us},
+                           "lookups_performed_per_candidate_per_pass": {"intersection": lk_inter, "priors": lk_prior},
+                           "note": "the term kernels are instruction-issue bound (sphere / box rejects and exact bound tests per "
+                                   "(point, SDF) pair) and their SDF working set is L2-resident: neither HBM nor gather bandwidth "
+                                   "is the limiter, see DESIGN.md"})
             g_cpu = None
             if not args.no_cpu_baseline:
                 o2 = tr._options_struct()
                 o2.numIterations = 10
-                tc0 = time.perf_counter()
-                n_cpu = 0
-                while time.perf_counter() - tc0 < 10.0 and n_cpu < 64:
-                    c = idx[n_cpu % len(idx)]
+                nthr = cpu_threads(args)
+
+                def one_candidate(k):
+                    c = idx[k % len(idx)]
                     O.optimize_poses_noobs(oms, [T_all[c, 0], T_all[c, 1]], [j_all[c], np.zeros(0, dtype=np.float32)], o2, clouds, pots, gs.priors)
-                    n_cpu += 1
-                cpu_t = time.perf_counter() - tc0
-                g_cpu = {"value": round(n_cpu * 10 / g_iters / cpu_t, 4), "unit": "grasps/s", "cores": 1, "kind": "port",
-                         "sample": "%d candidates x 10 of the %d iterations (+ getError), CPU oracle, 1 thread, scaled to %d iterations"
-                                   % (n_cpu, g_iters, g_iters)}
+
+                def time_cpu(threads, n):
+                    tc0 = time.perf_counter()
+                    if threads == 1:
+                        for k in range(n):
+                            one_candidate(k)
+                    else:       # candidates are independent: one per thread (ctypes releases the GIL during the call)
+                        from concurrent.futures import ThreadPoolExecutor
+                        with ThreadPoolExecutor(threads) as ex:
+                            list(ex.map(one_candidate, range(n)))
+                    return n * 10 / g_iters / (time.perf_counter() - tc0)
+                one = time_cpu(1, 16)
+                many = time_cpu(nthr, 16 * nthr)
+                sample = "candidates x 10 of the %d iterations (+ getError), CPU oracle, scaled to %d iterations" % (g_iters, g_iters)
+                g_cpu = {"value": round(many, 4), "unit": "grasps/s", "cores": nthr, "kind": "port", "cpu_model": cpu_model_name(),
+                         "sample": "%d %s, %d threads (one candidate per thread)" % (16 * nthr, sample, nthr),
+                         "single_thread": {"value": round(one, 4), "cores": 1, "sample": "16 %s, 1 thread" % sample}}
             grasps = {"metric": "batched ContactGrasp refinement", "value": round(n_cand * args.grasp_steps / g_elapsed, 2), "unit": "grasps/s",
                       "gn_iterations_per_s": round(n_cand * args.grasp_steps * g_iters / g_elapsed, 1),
                       "scaling": "strong", "n_candidates": n_cand, "candidates_per_gpu": len(idx), "iterations": g_iters,
@@ -318,15 +413,7 @@ def main():
                                              "intersection, %d iterations + getError, round-robin over %d GPU(s), one all-gather of "
                                              "{energy, pose}" % (n_cand, Q, g_iters, world)},
                       "best_candidates": [int(b) for b in best],
-                      "roofline": {"bound": "hbm", "kernel": g_name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": PMC_TRAFFIC.get(g_name),
-                                   "algorithmic_bytes_per_launch": round(bpl), "avg_launch_us": round(us, 2),
-                                   "per_step_us": {k: round(v, 2) for k, v in per_step_us.items()},
-                                   "per_kernel_achieved_GBs": {k: round(bytes_per_launch[k] / (per_launch_us[k] * 1e-6) / 1e9, 2)
-                                                               for k in bytes_per_launch if k in per_launch_us},
-                                   "lookups_per_candidate_per_iteration": {"intersection": lk_inter, "priors": lk_prior},
-                                   "note": "the term kernels are instruction-issue bound (sphere / box rejects and exact bound tests per "
-                                           "(point, SDF) pair), not bandwidth bound: see DESIGN.md"},
+                      "roofline": g_roof,
                       "cpu_baseline": g_cpu}
 
     # third leg: BASELINE configs[4] (Barrett 8->4 reduced + box object, 1280x720, multi-model tracking with observations):
@@ -376,7 +463,7 @@ def main():
                                    "prediction 320x240, 64^3 obs SDF, obs->mod + mod->obs, %d GN iterations per optimizePose call, "
                                    "normThreshold %.1f; one frame per GPU" % (iters, sc.opts.normThreshold),
                        "iterations_per_step": iters, "frames_per_gpu": 1, "parallelism": "independent frames, 1 per GPU"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "batched_grasps": grasps, "multi_model_tracking": multi,
+            "repeats": repeats, "roofline": roofline, "cpu_baseline": cpu_baseline, "batched_grasps": grasps, "multi_model_tracking": multi,
         }
         print(json.dumps(line, default=float))
     if distributed:

@@ -114,16 +114,42 @@ def fill_model_desc(desc_cls, host_model, model_id=0, obs_layout=None):
     return d, keep
 
 
+COUNT_LIB_PATH = os.path.join(_HERE, "libdartk_count.so")
 _lib = None
+_libs = {}
 
 
 def lib():
+    """The library every dart_amd call goes through: libdartk.so (or, inside `with counting_library():`, its diagnostic twin)."""
     global _lib
-    if _lib is not None:
+    if _lib is None:
+        _lib = _load(LIB_PATH)
+    return _lib
+
+
+class counting_library:
+    """with counting_library() as L: route all dart_amd calls through libdartk_count.so, the diagnostic build that counts the
+    trilinear lookups its kernels perform (dartk_lookup_counters). Model handles, device buffers and streams are shared
+    between the two libraries (same structs, same HIP runtime); each has its own workspace. Measurement only."""
+
+    def __enter__(self):
+        global _lib
+        self.prev = lib()
+        _lib = _load(COUNT_LIB_PATH)
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError("libdartk.so not built: run `python -m dart_amd.build` (the product path has no CPU fallback)")
-    L = C.CDLL(LIB_PATH)
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
+
+
+def _load(path):
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise RuntimeError("%s not built: run `python -m dart_amd.build` (the product path has no CPU fallback)" % os.path.basename(path))
+    L = C.CDLL(path)
     L.dartk_last_error.restype = C.c_char_p
     L.dartk_model_obs_sdf_data.restype = C.c_void_p
     vp = C.c_void_p
@@ -180,6 +206,7 @@ def lib():
         "dartk_optimize_poses": [C.POINTER(MultiOptionsC), C.POINTER(MultiModelC), vp, vp, C.c_int, C.c_int, vp, vp, vp, vp],
         "dartk_noobs_optimize_poses": [vp, C.POINTER(NoObsOptions), C.c_int, vp, vp, vp, vp, vp, vp],
         "dartk_noobs_get_error": [vp, C.POINTER(NoObsOptions), C.c_int, vp, vp, vp, vp],
+        "dartk_lookup_counters": [C.POINTER(C.c_uint64), C.c_int],
         "dartk_profile_begin": [],
         "dartk_profile_end": [c_float_p, c_int_p],
         "dartk_optimize_pose": [vp, vp, vp, C.c_int, C.c_int, C.POINTER(OptOptions), vp, C.c_int, vp, vp, vp, vp, vp],
@@ -189,7 +216,7 @@ def lib():
         fn.argtypes = args
         if name not in ("dartk_model_obs_sdf_data",):
             fn.restype = C.c_int
-    _lib = L
+    _libs[path] = L
     return L
 
 

@@ -126,7 +126,7 @@ fused_obs2mod_kernel(const float4 *__restrict__ vert, const float4 *__restrict__
             const SdfDev &s = m.sdfs[r.grid];
             const f3 xf = se3_apply_w(sT_fm + 12 * frame, r.xm.x, r.xm.y, r.xm.z, r.w);
             const f3 xg = grid_coords(s, xf);
-            gf = grid_gradient(m.grids + s.dataOff, s.dimx, s.dimy, xg);
+            gf = sdf_gradient<CNT_ASSOC_GRAD>(m.grids, s, xg);
             // normal test (obsToMod.cu:83-96), same arithmetic as normal_test()
             active = true;
             const float4 nObs = norm[index];
@@ -635,6 +635,8 @@ gn_solve_single_kernel(ModelView m, SolveArgs a) {
 static size_t solve_lds_bytes(int d, int nFrames) {
     return sizeof(float) * (size_t)(d * (d + 2) + 4 * d + 12 * nFrames + 8);
 }
+
+DARTK_COUNTER_ACCESS(gn)
 
 }  // namespace dartk
 

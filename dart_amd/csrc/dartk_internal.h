@@ -117,6 +117,26 @@ static constexpr int kMaxSys = (kMaxDims + 1) * (kMaxDims + 2) / 2;
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// every translation unit with SDF lookups defines lookup_counters_<name>(out[8], reset) through this macro (see CNT_*)
+#ifdef DARTK_COUNT_LOOKUPS
+#define DARTK_COUNTER_ACCESS(name)                                                                           \
+    int lookup_counters_##name(unsigned long long *out, int reset) {                                          \
+        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                                    \
+        DARTK_HIP(hipDeviceSynchronize());                                                                    \
+        DARTK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lookupCount), sizeof(h)));                              \
+        for (int i = 0; i < 8; ++i) { out[i] += h[i]; h[i] = 0; }                                             \
+        if (reset) DARTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_lookupCount), h, sizeof(h)));                     \
+        return DARTK_OK;                                                                                      \
+    }
+#else
+#define DARTK_COUNTER_ACCESS(name) int lookup_counters_##name(unsigned long long *, int) { return DARTK_OK; }
+#endif
+int lookup_counters_obs2mod(unsigned long long *out, int reset);
+int lookup_counters_gn(unsigned long long *out, int reset);
+int lookup_counters_mod2obs(unsigned long long *out, int reset);
+int lookup_counters_intersection(unsigned long long *out, int reset);
+int lookup_counters_noobs(unsigned long long *out, int reset);
+
 // ---- device helpers -------------------------------------------------------------------------------
 #ifdef __HIPCC__
 
@@ -208,8 +228,21 @@ __device__ __forceinline__ bool in_keep_box(const SdfDev &s, int slot, f3 g) {
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return a + t * (b - a); }
 struct __attribute__((packed, aligned(4))) f2u { float a, b; };   // x-neighbours fetched with one 8-byte load
 
+// ---- lookup counters (diagnostic build -DDARTK_COUNT_LOOKUPS = libdartk_count.so only; bench.py's roofline leg prices the
+// trilinear lookups the kernels PERFORM, not the ones the reference's un-pruned loops imply). One array per translation unit
+// (no relocatable device code), summed by dartk_lookup_counters(). Categories follow the oracle's (oracle/dart_oracle.h).
+enum { CNT_OTHER = 0, CNT_ASSOC = 1, CNT_ASSOC_GRAD = 2, CNT_NE_O2M = 3, CNT_RAYCAST = 4, CNT_M2O = 5, CNT_INTER = 6, CNT_PRIOR = 7, CNT_N = 8 };
+#ifdef DARTK_COUNT_LOOKUPS
+static __device__ unsigned long long g_lookupCount[CNT_N];
+template <int CAT> __device__ __forceinline__ void count_lookup() { atomicAdd(&g_lookupCount[CAT], 1ull); }
+#else
+template <int CAT> __device__ __forceinline__ void count_lookup() {}
+#endif
+
 // getValueInterpolated (grid_3d.h:86-112); data points at voxel (0,0,0) of the grid
+template <int CAT = CNT_OTHER>
 __device__ __forceinline__ float grid_value(const float *__restrict__ data, int dimx, int dimy, f3 g) {
+    count_lookup<CAT>();
     const float tx = g.x - 0.5f, ty = g.y - 0.5f, tz = g.z - 0.5f;
     const int x0 = (int)tx, y0 = (int)ty, z0 = (int)tz;
     const float fx = tx - (float)x0, fy = ty - (float)y0, fz = tz - (float)z0;
@@ -230,18 +263,29 @@ __device__ __forceinline__ float grid_value(const float *__restrict__ data, int 
     return lerpf(dxy0, dxy1, fz);
 }
 // getGradientInterpolated (grid_3d.h:314-330): six interpolated lookups at +-1 voxel, 0.5*(f+ - f-)
+template <int CAT = CNT_OTHER>
 __device__ __forceinline__ f3 grid_gradient(const float *__restrict__ data, int dimx, int dimy, f3 g) {
     f3 q, r;
-    q = g; q.x = g.x + 1.0f; const float fpx = grid_value(data, dimx, dimy, q);
-    q = g; q.y = g.y + 1.0f; const float fpy = grid_value(data, dimx, dimy, q);
-    q = g; q.z = g.z + 1.0f; const float fpz = grid_value(data, dimx, dimy, q);
-    q = g; q.x = g.x - 1.0f; const float fmx = grid_value(data, dimx, dimy, q);
-    q = g; q.y = g.y - 1.0f; const float fmy = grid_value(data, dimx, dimy, q);
-    q = g; q.z = g.z - 1.0f; const float fmz = grid_value(data, dimx, dimy, q);
+    q = g; q.x = g.x + 1.0f; const float fpx = grid_value<CAT>(data, dimx, dimy, q);
+    q = g; q.y = g.y + 1.0f; const float fpy = grid_value<CAT>(data, dimx, dimy, q);
+    q = g; q.z = g.z + 1.0f; const float fpz = grid_value<CAT>(data, dimx, dimy, q);
+    q = g; q.x = g.x - 1.0f; const float fmx = grid_value<CAT>(data, dimx, dimy, q);
+    q = g; q.y = g.y - 1.0f; const float fmy = grid_value<CAT>(data, dimx, dimy, q);
+    q = g; q.z = g.z - 1.0f; const float fmz = grid_value<CAT>(data, dimx, dimy, q);
     r.x = 0.5f * (fpx - fmx);
     r.y = 0.5f * (fpy - fmy);
     r.z = 0.5f * (fpz - fmz);
     return r;
+}
+
+// lookups in one of a model's SDFs (grids = the model's grid arena)
+template <int CAT = CNT_OTHER>
+__device__ __forceinline__ float sdf_value(const float *__restrict__ grids, const SdfDev &s, f3 g) {
+    return grid_value<CAT>(grids + s.dataOff, s.dimx, s.dimy, g);
+}
+template <int CAT = CNT_OTHER>
+__device__ __forceinline__ f3 sdf_gradient(const float *__restrict__ grids, const SdfDev &s, f3 g) {
+    return grid_gradient<CAT>(grids + s.dataOff, s.dimx, s.dimy, g);
 }
 
 // ---- articulated Jacobian (kernel_common.h:12-71) ---------------------------------------------------

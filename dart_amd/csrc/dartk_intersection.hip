@@ -45,7 +45,7 @@ ne_self_intersection_kernel(const float4 *__restrict__ sites, int nSites, ModelV
             float *row = rows + slot * ld;
             const SdfDev &s = m.sdfs[c.dstGrid];
             const int dstFrame = m.sdfFrame[c.dstGrid];
-            const f3 gf = grid_gradient(m.grids + s.dataOff, s.dimx, s.dimy, c.vg);
+            const f3 gf = sdf_gradient<CNT_INTER>(m.grids, s, c.vg);
             const f3 gm = se3_rotate(sT_mf + 12 * dstFrame, gf);
             float *Jfull = RED ? (sFull + threadIdx.x * fullLd) : row;
             error_jacobian<true>(Jfull, vm, 1.0f, m.depMask[srcFrame], gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
@@ -107,7 +107,7 @@ ne_intersection_kernel(const float4 *__restrict__ sites, int nSites, ModelView s
             float *row = rows + slot * ld;
             const SdfDev &s = dst.sdfs[c.dstGrid];
             const int dstFrame = dst.sdfFrame[c.dstGrid];
-            const f3 gf = grid_gradient(dst.grids + s.dataOff, s.dimx, s.dimy, c.vg);
+            const f3 gf = sdf_gradient<CNT_INTER>(dst.grids, s, c.vg);
             const f3 gdm = se3_rotate(dT_mf + 12 * dstFrame, gf);
             const f3 gsm = se3_rotate(T_sd, gdm);
             float *Jfull = RED ? (sFull + threadIdx.x * fullLd) : row;
@@ -299,6 +299,8 @@ int gn_launch_ne_self(const float *d_sites, int nSites, const ModelView &m, cons
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
+
+DARTK_COUNTER_ACCESS(intersection)
 
 }  // namespace dartk
 

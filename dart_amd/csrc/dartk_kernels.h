@@ -89,7 +89,7 @@ __device__ __forceinline__ AssocResult associate_point(const ModelView &m, float
         const SdfDev &s = m.sdfs[g];
         const f3 xg = grid_coords(s, xf);
         if (!in_bounds_grad_interp(s, xg) || !in_keep_box(s, slot, xg)) continue;
-        const float d = grid_value(m.grids + s.dataOff, s.dimx, s.dimy, xg) * s.res;
+        const float d = sdf_value<CNT_ASSOC>(m.grids, s, xg) * s.res;
         if (d < best) { best = d; grid = g; }
     }
     if (best * best > distThr * distThr) grid = -1;   // obsToMod.cu:75 (1e20^2 = inf also lands here)
@@ -106,7 +106,7 @@ __device__ __forceinline__ bool normal_test(const ModelView &m, const AssocResul
     const float *__restrict__ T_fm = m.T_fm + 12 * f;
     const f3 xf = se3_apply_w(T_fm, r.xm.x, r.xm.y, r.xm.z, r.w);
     const f3 xg = grid_coords(s, xf);
-    const f3 gr = grid_gradient(m.grids + s.dataOff, s.dimx, s.dimy, xg);
+    const f3 gr = sdf_gradient<CNT_ASSOC_GRAD>(m.grids, s, xg);
     float T_mc[12], T_fc[12], T_cf[12], T_f[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) { T_mc[i] = m.T_mc[i]; T_f[i] = T_fm[i]; }
@@ -185,7 +185,7 @@ __device__ __forceinline__ Collision first_collision(const ModelView &dst, const
                 const f3 vd = se3_apply_w(T_fm_dst + 12 * f, v_dm.x, v_dm.y, v_dm.z, 1.0f);
                 const f3 vg = grid_coords(s, vd);
                 if (in_bounds_grad_interp(s, vg) && in_keep_box(s, 0, vg)) {       // r < 0 needs a negative corner
-                    const float r = grid_value(dst.grids + s.dataOff, s.dimx, s.dimy, vg) * s.res;
+                    const float r = sdf_value<CNT_INTER>(dst.grids, s, vg) * s.res;
                     if (r < 0) { c.hit = true; c.dstGrid = g; c.residual = r; c.vg = vg; cand = 0ull; }
                 }
             }
@@ -200,7 +200,7 @@ __device__ __forceinline__ Collision first_collision(const ModelView &dst, const
         const f3 vd = se3_apply_w(T_fm_dst + 12 * f, v_dm.x, v_dm.y, v_dm.z, 1.0f);
         const f3 vg = grid_coords(s, vd);
         if (!in_bounds_grad_interp(s, vg) || !in_keep_box(s, 0, vg)) continue;     // r < 0 needs a negative corner
-        const float r = grid_value(dst.grids + s.dataOff, s.dimx, s.dimy, vg) * s.res;
+        const float r = sdf_value<CNT_INTER>(dst.grids, s, vg) * s.res;
         if (r < 0) { c.hit = true; c.dstGrid = g; c.residual = r; c.vg = vg; break; }
     }
     return c;

@@ -122,7 +122,7 @@ raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int 
             xg.x = fmaxf(1.0f, fminf(xg.x, hix));
             xg.y = fmaxf(1.0f, fminf(xg.y, hiy));
             xg.z = fmaxf(1.0f, fminf(xg.z, hiz));
-            return grid_value(data, dimx, dimy, xg) * res;
+            return grid_value<CNT_RAYCAST>(data, dimx, dimy, xg) * res;
         };
         float sdfValPrev = eval(t0);
         float tPrev = t0;
@@ -537,7 +537,7 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
                 pm = se3_apply(T_gc, p3);
                 pg = grid_coords(obs, pm);
                 if (in_bounds_grad_interp(obs, pg)) {
-                    residual = grid_value(obsData, obs.dimx, obs.dimy, pg) * obs.res;
+                    residual = grid_value<CNT_M2O>(obsData, obs.dimx, obs.dimy, pg) * obs.res;
                     bool ok = true;
                     if (TRUNC) ok = !(residual >= truncationDist || residual < 0);
                     if (ok) {
@@ -554,7 +554,7 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
         const int slot = compact_slot<NE_BLOCK>(active, waveCnt, nActive);
         if (active) {
             float *row = rows + slot * ld;
-            const f3 gm = grid_gradient(obsData, obs.dimx, obs.dimy, pg);
+            const f3 gm = grid_gradient<CNT_M2O>(obsData, obs.dimx, obs.dimy, pg);
             float *Jfull = RED ? (sFull + threadIdx.x * fullLd) : row;
             error_jacobian<false>(Jfull, pm, 1.0f, m.depMask[frame], gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
             if (RED) reduce_jacobian<RED>(row, Jfull, 6, fullDims, redDims, dtheta_dalpha, mapping);
@@ -775,6 +775,8 @@ error_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, ModelView m, dou
     }
     if (threadIdx.x == 0) blockSums[blockIdx.x] = red[0];
 }
+
+DARTK_COUNTER_ACCESS(mod2obs)
 
 }  // namespace dartk
 

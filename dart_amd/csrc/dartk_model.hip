@@ -482,6 +482,26 @@ int dartk_model_get_transforms(dartk_model_t h, float *h_T_mc, float *h_T_mf, fl
     return DARTK_OK;
 }
 
+// diagnostic library only (built with -DDARTK_COUNT_LOOKUPS): trilinear lookups performed since the last reset, by category
+int dartk_lookup_counters(uint64_t *h_counts, int reset) {
+    DARTK_REQUIRE(h_counts, "dartk_lookup_counters: null argument");
+#ifdef DARTK_COUNT_LOOKUPS
+    unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int rc;
+    if ((rc = lookup_counters_obs2mod(tot, reset))) return rc;
+    if ((rc = lookup_counters_gn(tot, reset))) return rc;
+    if ((rc = lookup_counters_mod2obs(tot, reset))) return rc;
+    if ((rc = lookup_counters_intersection(tot, reset))) return rc;
+    if ((rc = lookup_counters_noobs(tot, reset))) return rc;
+    for (int i = 0; i < 8; ++i) h_counts[i] = tot[i];
+    return DARTK_OK;
+#else
+    (void)reset;
+    set_error("dartk_lookup_counters: this library was built without lookup counters (load libdartk_count.so)");
+    return DARTK_ERR_UNSUPPORTED;
+#endif
+}
+
 int dartk_model_num_sdfs(dartk_model_t h) { return h ? reinterpret_cast<Model *>(h)->v.nSdfs : 0; }
 int dartk_model_dims(dartk_model_t h) { return h ? 6 + reinterpret_cast<Model *>(h)->v.nJoints : 0; }
 float *dartk_model_obs_sdf_data(dartk_model_t h) { return h ? reinterpret_cast<Model *>(h)->v.obsData : nullptr; }

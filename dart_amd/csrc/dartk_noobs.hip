@@ -290,7 +290,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                 const Collision col = first_collision(src, sTf(T.src), pm, potPtr, srcGrid, sSph(T.src));
                 if (col.hit) {
                     const SdfDev &s = src.sdfs[col.dstGrid];
-                    const f3 gf = grid_gradient(src.grids + s.dataOff, s.dimx, s.dimy, col.vg);
+                    const f3 gf = sdf_gradient<CNT_INTER>(src.grids, s, col.vg);
                     gs = se3_rotate(sTf(T.src) + 12 * src.nFrames + 12 * src.sdfFrame[col.dstGrid], gf);
                     residual = col.residual;
                     active = true;
@@ -304,7 +304,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                 const Collision col = first_collision(dst, sTf(T.dst), vdm, nullptr, 0, sSph(T.dst));
                 if (col.hit) {
                     const SdfDev &s = dst.sdfs[col.dstGrid];
-                    const f3 gf = grid_gradient(dst.grids + s.dataOff, s.dimx, s.dimy, col.vg);
+                    const f3 gf = sdf_gradient<CNT_INTER>(dst.grids, s, col.vg);
                     const f3 gd = se3_rotate(sTf(T.dst) + 12 * dst.nFrames + 12 * dst.sdfFrame[col.dstGrid], gf);
                     gs = se3_rotate(sT_ds + 12, gd);
                     residual = col.residual;
@@ -381,7 +381,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                         const f3 df = se3_apply_w(dfm + 12 * mdFrame[ds], pdm.x, pdm.y, pdm.z, 1.0f);
                         const f3 g = grid_coords(s, df);
                         if (!in_bounds_interp(s, g) || !in_keep_box(s, slot, g)) continue;
-                        const float v = grid_value(md.grids + s.dataOff, s.dimx, s.dimy, g);
+                        const float v = sdf_value<CNT_PRIOR>(md.grids, s, g);
                         if (v < minV) { minV = v; dstSdf = ds; }
                     }
                     if (dstSdf >= 0) {
@@ -390,11 +390,11 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                         const f3 cdf = se3_apply_w(dfm + 12 * dstFrame, pdm.x, pdm.y, pdm.z, 1.0f);
                         const f3 cg = grid_coords(s, cdf);
                         if (in_bounds_grad_interp(s, cg)) {
-                            float err = grid_value(md.grids + s.dataOff, s.dimx, s.dimy, cg) * s.res;
+                            float err = sdf_value<CNT_PRIOR>(md.grids, s, cg) * s.res;
                             if (!(fabsf(err) > pr.contactThreshold)) {
                                 if ((double)fabsf(err) < 1e-4) E = 0.0f;       // :70-73
                                 else {
-                                    const f3 g_df = grid_gradient(md.grids + s.dataOff, s.dimx, s.dimy, cg);
+                                    const f3 g_df = sdf_gradient<CNT_PRIOR>(md.grids, s, cg);
                                     gdm = se3_rotate(dmf + 12 * dstFrame, g_df);
                                     const f3 g_c = se3_rotate(sPoseT(pDst, md.nSdfs) + 12, gdm);
                                     gs = se3_rotate(sPoseT(pSrc, ms.nSdfs), g_c);
@@ -621,6 +621,8 @@ struct NoObs {
     size_t ldsTerm[NOOBS_MAX_TERMS], ldsSolve;
     bool lambdaActive[DARTK_MAX_MODELS * DARTK_MAX_MODELS];
 };
+
+DARTK_COUNTER_ACCESS(noobs)
 
 }  // namespace dartk
 

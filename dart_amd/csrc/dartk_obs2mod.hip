@@ -101,7 +101,7 @@ assoc_multi_kernel(const float4 *__restrict__ vert, int nPix, const MultiArgs *_
                     const SdfDev &s = m.sdfs[g];
                     const f3 xg = grid_coords(s, xf);
                     if (!in_bounds_grad_interp(s, xg) || !in_keep_box(s, slot, xg)) continue;
-                    const float d = grid_value(m.grids + s.dataOff, s.dimx, s.dimy, xg) * s.res;
+                    const float d = sdf_value<CNT_ASSOC>(m.grids, s, xg) * s.res;
                     if (d < sdfError) {
                         if (d * d < thr * thr) { sdfError = d; aGrid = g; aModel = mi; }
                     }
@@ -176,7 +176,7 @@ ne_obs2mod_kernel(const dartk_da_point *__restrict__ pts, const float4 *__restri
             const f3 xf = se3_apply_w(sT_fm + 12 * frame, xm.x, xm.y, xm.z, xc.w);
             const SdfDev s = sSdf[g];
             const f3 xg = grid_coords(s, xf);
-            const f3 gf = grid_gradient(m.grids + s.dataOff, s.dimx, s.dimy, xg);
+            const f3 gf = sdf_gradient<CNT_NE_O2M>(m.grids, s, xg);
             const f3 gm = se3_rotate(sT_mf + 12 * frame, gf);
             float *Jfull = RED ? (sFull + threadIdx.x * fullLd) : row;
             error_jacobian<false>(Jfull, xm, xc.w, m.depMask[frame], gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
@@ -383,6 +383,8 @@ int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
+
+DARTK_COUNTER_ACCESS(obs2mod)
 
 }  // namespace dartk
 

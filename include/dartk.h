@@ -347,6 +347,11 @@ enum dartk_prof_class {
     DARTK_PROF_NOOBS_TERMS = 9 /* self- and pairwise intersection term kernels */, DARTK_PROF_NOOBS_SOLVE = 10,
     DARTK_PROF_NOOBS_PRIORS = 11 /* contact-prior term kernel */, DARTK_PROF_CLASSES = 12
 };
+/* Trilinear SDF lookups actually performed by the kernels since the last reset, by category: h_counts[8] = {other, association
+ * scan, association gradient (normal test / fused Jacobian), obs->mod gradient, ray-cast march, mod->obs (value + gradient),
+ * intersection, contact priors}. Only the diagnostic build libdartk_count.so (-DDARTK_COUNT_LOOKUPS, one atomic per lookup)
+ * counts; libdartk.so returns DARTK_ERR_UNSUPPORTED. Model handles are interchangeable between the two libraries. */
+int dartk_lookup_counters(uint64_t *h_counts, int reset);
 int dartk_profile_begin(void);
 int dartk_profile_end(float *h_ms_total /*[DARTK_PROF_CLASSES]*/, int32_t *h_launches /*[DARTK_PROF_CLASSES]*/);
 
