@@ -148,7 +148,8 @@ def main():
     ap.add_argument("--grasp-steps", type=int, default=3)
     ap.add_argument("--no-grasps", action="store_true")
     ap.add_argument("--no-multi-model", action="store_true", help="skip the config-5 (two-model tracking) leg")
-    ap.add_argument("--multi-steps", type=int, default=20)
+    ap.add_argument("--multi-steps", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=256, help="frames of the config-5 batch (sharded by index over the ranks)")
     ap.add_argument("--no-tracking", action="store_true", help="profiling aid: skip the headline leg's timed loop")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="test aid for a 1-GPU box: every rank uses cuda:0 and the ranks talk over gloo (RCCL refuses two ranks on one device); "
@@ -416,42 +417,56 @@ def main():
                       "roofline": g_roof,
                       "cpu_baseline": g_cpu}
 
-    # third leg: BASELINE configs[4] (Barrett 8->4 reduced + box object, 1280x720, multi-model tracking with observations):
-    # the device-resident Optimizer::optimizePoses loop, one independent frame per GPU (weak scaling), no collective
+    # third leg: BASELINE configs[4] (Barrett 8->4 reduced + box object, 1280x720, multi-model tracking with observations), a
+    # batch of independent frames sharded by frame index over the ranks: every launch of the device-resident
+    # Optimizer::optimizePoses loop covers all frames of the rank (dartk_optimize_poses_batch); one all-gather of the poses
     multi = None
     if not args.no_multi_model:
-        from dart_amd.optimizer import synthetic_observation
         m_iters = 10
-        msc = configs.config5(1280, 720, rank)
+        n_frames = args.frames
+        f_idx = sharding.shard_indices(n_frames, rank, world)
+        msc = configs.config5(1280, 720, 0)
         mtr = configs.make_multi_tracker(msc)
-        for m, (T, a) in enumerate(msc.true):
-            mtr.getPose(m).setTransformCameraToModel(T)
-            mtr.getPose(m).getReducedArticulation()[:] = a
-            mtr.updatePose(m)
-        _, mvert, mnorm = synthetic_observation(mtr.models, msc.width, msc.height, msc.fl, msc.pp)
         mtr.getOptions().numIterations = m_iters
+        mvert, mnorm, mT0, ma0 = configs.config5_batch(mtr, msc, f_idx)
+        mT0_d, ma0_d = torch.from_numpy(mT0).to(dev), torch.from_numpy(ma0).to(dev)
 
         def mstep():
-            for m, (T, a) in enumerate(msc.init):
-                mtr.getPose(m).setTransformCameraToModel(T)
-                mtr.getPose(m).getReducedArticulation()[:] = a
-            mtr.optimizePosesDevice(mvert, mnorm)
+            T_o, a_o = mtr.optimizePosesBatch(mvert, mnorm, mT0_d, ma0_d)
+            rec_ = torch.cat([T_o.reshape(len(f_idx), -1), a_o], dim=1)
+            return sharding.gather_candidates(n_frames, rank, world, torch.zeros(len(f_idx), device=dev), rec_)    # RCCL all-gather of the poses
 
-        for _ in range(2):
-            mstep()
+        mstep()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.multi_steps):
             mstep()
         barrier()
         m_elapsed = max_over_ranks(time.perf_counter() - t0)
+        # the same frames one at a time through the single-frame device loop (what round 1 measured), on a sample
+        single_its = None
         if rank == 0:
-            multi = {"metric": "multi-model tracking (device-resident optimizePoses)", "unit": "GN iterations/s",
-                     "value": round(world * args.multi_steps * m_iters / m_elapsed, 2), "scaling": "weak", "steps": args.multi_steps,
-                     "ms_per_step": round(1000.0 * m_elapsed / args.multi_steps, 4), "iterations_per_step": m_iters,
-                     "config": {"workload": "BASELINE configs[4]: Barrett hand (8 joints reduced to 4, proxy geometry) + box object, "
-                                            "synthetic 1280x720 depth, obs->mod + mod->obs + self / pairwise intersection in reduced "
-                                            "dimensions, %d GN iterations per optimizePoses call incl. the pose reset; one frame per GPU" % m_iters}}
+            n_s = min(len(f_idx), 8)
+            for m in range(2):
+                mtr.getPose(m).setTransformCameraToModel(mT0[0, m])
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            for k in range(n_s):
+                for m in range(2):
+                    mtr.getPose(m).setTransformCameraToModel(mT0[k, m])
+                mtr.getPose(0).getReducedArticulation()[:] = ma0[k]
+                mtr.optimizePosesDevice(mvert[k], mnorm[k])
+            torch.cuda.synchronize()
+            single_its = n_s * m_iters / (time.perf_counter() - ts0)
+            multi = {"metric": "multi-model tracking, batch of independent frames (dartk_optimize_poses_batch)", "unit": "GN iterations/s",
+                     "value": round(n_frames * args.multi_steps * m_iters / m_elapsed, 2),
+                     "frames_per_s": round(n_frames * args.multi_steps / m_elapsed, 2), "scaling": "strong", "n_frames": n_frames,
+                     "frames_per_gpu": len(f_idx), "steps": args.multi_steps, "ms_per_step": round(1000.0 * m_elapsed / args.multi_steps, 3),
+                     "iterations_per_step": m_iters, "single_frame_loop_GN_its": round(single_its, 2),
+                     "config": {"workload": "BASELINE configs[4]: %d frames of Barrett hand (8 joints reduced to 4, proxy geometry) + box object, "
+                                            "synthetic 1280x720 depth per frame, obs->mod + mod->obs + self / pairwise intersection in reduced "
+                                            "dimensions, %d GN iterations per frame, frames sharded by index over %d GPU(s), one all-gather of "
+                                            "the poses; single_frame_loop_GN_its = the same frames one call at a time" % (n_frames, m_iters, world)}}
 
     if rank == 0:
         value = world * n_steps * iters / elapsed if n_steps else 0.0

@@ -280,14 +280,9 @@ def barrett_reduction(hand):
     return LinearPoseReduction(Fd, R, A, np.zeros(Fd, dtype=F), lim[:R, 0], lim[:R, 1], hand.joint_names[:R])
 
 
-def config5(width=1280, height=720, frame=0):
+def config5_poses(frame, red):
+    """True and start poses [(T_mc, reduced articulation)] x 2 models of frame `frame` of the config-5 sequence (seeded)."""
     rng = np.random.default_rng(SEED + 5 + frame)
-    hand = load_asset("barrett").voxelize(0.005, 0.10)
-    obj = _object_model()
-    pot, _ = _hand_potential("barrett", len(hand.sdfs))
-    red = barrett_reduction(hand)
-    s = width / 640.0
-    fl = (FOCAL * s, FOCAL * s)
     art = np.array([0.3, 0.9, 0.8, 1.0], dtype=F) * (0.8 + 0.4 * rng.random(4)).astype(F)
     art = np.clip(art, [red.getMin(i) for i in range(4)], [red.getMax(i) for i in range(4)]).astype(F)
     T_cm_h = se3.mul(se3.translation(-0.05, 0.02, 0.55), se3.exp(np.array([0, 0, 0, 1.3, 0.3, -0.2], dtype=F)))
@@ -298,7 +293,39 @@ def config5(width=1280, height=720, frame=0):
         lim = np.stack([[red.getMin(i), red.getMax(i)] for i in range(len(a))]) if len(a) else None
         T, j = _perturb(T_mc, a.astype(np.float64), lim, rng, 0.012, 3.0, 0.08)
         init.append((T, j))
+    return true, init
+
+
+def config5(width=1280, height=720, frame=0):
+    hand = load_asset("barrett").voxelize(0.005, 0.10)
+    obj = _object_model()
+    pot, _ = _hand_potential("barrett", len(hand.sdfs))
+    red = barrett_reduction(hand)
+    s = width / 640.0
+    fl = (FOCAL * s, FOCAL * s)
+    true, init = config5_poses(frame, red)
     return MultiScene("C5-barrett-object", hand, obj, red, pot, width, height, fl, (width / 2, height / 2), true, init, 5)
+
+
+def config5_batch(tr, sc, frame_ids):
+    """Synthetic observations and start poses of the frames `frame_ids` of the config-5 sequence for a tracker built from `sc`:
+    (vert [F,H,W,4], norm [F,H,W,4] CUDA tensors, T_mcs [F,2,12], reduced articulations [F,4]). The observation of a frame is
+    the ray-cast of its true pose, generated on the device."""
+    import torch
+    from .optimizer import synthetic_observation
+    verts, norms, T0, a0 = [], [], [], []
+    for k in frame_ids:
+        true, init = config5_poses(int(k), sc.reduction)
+        for m, (T, a) in enumerate(true):
+            tr.getPose(m).setTransformCameraToModel(T)
+            tr.getPose(m).getReducedArticulation()[:] = a
+            tr.updatePose(m)
+        _, v, n = synthetic_observation(tr.models, sc.width, sc.height, sc.fl, sc.pp)
+        verts.append(v.clone())
+        norms.append(n.clone())
+        T0.append(np.stack([T for T, _ in init]))
+        a0.append(np.concatenate([a for _, a in init]))
+    return torch.stack(verts).contiguous(), torch.stack(norms).contiguous(), np.stack(T0).astype(F), np.stack(a0).astype(F)
 
 
 def make_multi_tracker(sc):

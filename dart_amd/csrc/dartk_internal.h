@@ -63,6 +63,10 @@ struct ModelView {
     float *joints;    // [nJoints] (clamped)
     SdfDev obs;       // observation SDF header (dataOff unused)
     float *obsData;
+    // Batches of independent frames (dartk_optimize_poses_batch): the pose arrays above point at frame 0 of per-frame records
+    // [T_mc | T_cm | T_mf | T_fm | joints] that lie poseStride floats apart, the observation SDF at frame 0 of grids obsStride
+    // floats apart; kernels launched with grid.y = frames call select_frame(). Both are 0 for a model handle's own pose.
+    int poseStride, obsStride;
 };
 
 struct Model {        // host-side handle (dartk_model_t)
@@ -139,6 +143,13 @@ int lookup_counters_noobs(unsigned long long *out, int reset);
 
 // ---- device helpers -------------------------------------------------------------------------------
 #ifdef __HIPCC__
+
+// rebase a (local copy of a) ModelView on frame f of a batch (no-op for f == 0 or a plain model handle)
+__device__ __forceinline__ void select_frame(ModelView &m, int f) {
+    const size_t o = (size_t)f * (size_t)m.poseStride;
+    m.T_mc += o; m.T_cm += o; m.T_mf += o; m.T_fm += o; m.joints += o;
+    m.obsData += (size_t)f * (size_t)m.obsStride;
+}
 
 struct f3 { float x, y, z; };
 

@@ -9,10 +9,12 @@ namespace dartk {
 // SELF: articulation-only system of size dims-6 (intersection.cu:66-300).
 template <int PPT, int RED>
 __global__ void __launch_bounds__(NE_BLOCK)
-ne_self_intersection_kernel(const float4 *__restrict__ sites, int nSites, ModelView m, const int *__restrict__ pot,
+ne_self_intersection_kernel(const float4 *__restrict__ sites, int nSites, ModelView m_in, const int *__restrict__ pot,
                             int redDims, const float *__restrict__ dtheta_dalpha, const int *__restrict__ mapping,
                             float *__restrict__ slabs) {
     extern __shared__ float lds[];
+    ModelView m = m_in;
+    select_frame(m, blockIdx.y);                    // frame of a batch (0 otherwise)
     const int fullDims = 6 + m.nJoints;
     const int d = (RED ? redDims : fullDims) - 6;
     const int ld = row_len(d, false);
@@ -58,16 +60,20 @@ ne_self_intersection_kernel(const float4 *__restrict__ sites, int nSites, ModelV
         if (nActive) acc.accumulate(rows, ld, nActive);
         __syncthreads();
     }
-    acc.store(slabs + (size_t)blockIdx.x * sys_size(d), sys_size(d));
+    acc.store(slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * sys_size(d), sys_size(d));
 }
 
 // INTER-MODEL: source cloud in destination SDFs, full source-pose system (intersection.cu:367-597).
 template <int PPT, int RED>
 __global__ void __launch_bounds__(NE_BLOCK)
-ne_intersection_kernel(const float4 *__restrict__ sites, int nSites, ModelView src, ModelView dst,
+ne_intersection_kernel(const float4 *__restrict__ sites, int nSites, ModelView src_in, ModelView dst_in,
                        const float *__restrict__ T_ds_sd /* [24] */, int redDims, const float *__restrict__ dtheta_dalpha,
-                       const int *__restrict__ mapping, float *__restrict__ slabs) {
+                       const int *__restrict__ mapping, float *__restrict__ slabs, int tabStride) {
     extern __shared__ float lds[];
+    ModelView src = src_in, dst = dst_in;
+    select_frame(src, blockIdx.y);                  // frame of a batch (0 otherwise)
+    select_frame(dst, blockIdx.y);
+    T_ds_sd += (size_t)blockIdx.y * tabStride;
     const int fullDims = 6 + src.nJoints;
     const int d = RED ? redDims : fullDims;
     const int ld = row_len(d, false);
@@ -121,7 +127,7 @@ ne_intersection_kernel(const float4 *__restrict__ sites, int nSites, ModelView s
         if (nActive) acc.accumulate(rows, ld, nActive);
         __syncthreads();
     }
-    acc.store(slabs + (size_t)blockIdx.x * sys_size(d), sys_size(d));
+    acc.store(slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * sys_size(d), sys_size(d));
 }
 
 // counters (intersection.cu:11-64, :315-365)
@@ -169,10 +175,15 @@ static int launch_self(const float *d_sites, int nSites, int fullDims, int redDi
     Workspace *ws;
     int rc = get_workspace(&ws);
     if (rc) return rc;
-    if (nSites == 0) { DARTK_HIP(hipMemsetAsync(d_result, 0, S * sizeof(float), st)); return DARTK_OK; }
+    const FrameBatch fb = cur_batch();
+    if (nSites == 0) {
+        for (int f = 0; f < fb.n; ++f) DARTK_HIP(hipMemsetAsync(d_result + (size_t)f * fb.sys, 0, S * sizeof(float), st));
+        return DARTK_OK;
+    }
     const int nTiles = (nSites + NE_BLOCK - 1) / NE_BLOCK;
-    const int nBlocks = nTiles < kMaxPartialBlocks ? nTiles : kMaxPartialBlocks;
-    rc = ensure_partials(ws, (size_t)nBlocks * S);
+    const int cap = fb.n > 1 ? 64 : kMaxPartialBlocks;      // a batch fills the chip with its frames
+    const int nBlocks = nTiles < cap ? nTiles : cap;
+    rc = ensure_partials(ws, (size_t)fb.n * nBlocks * S);
     if (rc) return rc;
     size_t words = 24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8;
     if (RED) words += (size_t)NE_BLOCK * ((fullDims - 6) | 1);
@@ -183,7 +194,7 @@ static int launch_self(const float *d_sites, int nSites, int fullDims, int redDi
         auto kfn = ne_self_intersection_kernel<PPT_, RED>;                                                      \
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
-        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, m, d_pot, \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks, fb.n), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, m, d_pot, \
                            redDims, d_A, d_map, lane_partials(ws));                                                  \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_SELF(3);
@@ -225,10 +236,15 @@ static int launch_inter_dev(const float *d_sites, int nSites, int fullDims, int 
     Workspace *ws;
     int rc = get_workspace(&ws);
     if (rc) return rc;
-    if (nSites == 0) { DARTK_HIP(hipMemsetAsync(d_result, 0, S * sizeof(float), st)); return DARTK_OK; }
+    const FrameBatch fb = cur_batch();
+    if (nSites == 0) {
+        for (int f = 0; f < fb.n; ++f) DARTK_HIP(hipMemsetAsync(d_result + (size_t)f * fb.sys, 0, S * sizeof(float), st));
+        return DARTK_OK;
+    }
     const int nTiles = (nSites + NE_BLOCK - 1) / NE_BLOCK;
-    const int nBlocks = nTiles < kMaxPartialBlocks ? nTiles : kMaxPartialBlocks;
-    rc = ensure_partials(ws, (size_t)nBlocks * S);
+    const int cap = fb.n > 1 ? 64 : kMaxPartialBlocks;      // a batch fills the chip with its frames
+    const int nBlocks = nTiles < cap ? nTiles : cap;
+    rc = ensure_partials(ws, (size_t)fb.n * nBlocks * S);
     if (rc) return rc;
     size_t words = 24 * (size_t)(ms.nFrames + md.nFrames) + (size_t)NE_BLOCK * row_len(d, false) + 8;
     if (RED) words += (size_t)NE_BLOCK * (fullDims | 1);
@@ -239,8 +255,8 @@ static int launch_inter_dev(const float *d_sites, int nSites, int fullDims, int 
         auto kfn = ne_intersection_kernel<PPT_, RED>;                                                           \
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
-        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, ms, md,   \
-                           d_T_ds_sd, redDims, d_A, d_map, lane_partials(ws));                                       \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks, fb.n), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, ms, md, \
+                           d_T_ds_sd, redDims, d_A, d_map, lane_partials(ws), fb.tab);                               \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_INTER(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_INTER(6);
@@ -251,8 +267,11 @@ static int launch_inter_dev(const float *d_sites, int nSites, int fullDims, int 
 }
 
 // T_ds = T_mc(dst) * T_cm(src) and its inverse from the models' device poses (optimizer.cpp:396-397)
-__global__ void pair_transform_kernel(ModelView src, ModelView dst, float *__restrict__ out24) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void pair_transform_kernel(ModelView src, ModelView dst, float *__restrict__ out24, int tabStride) {
+    if (threadIdx.x != 0) return;
+    select_frame(src, blockIdx.x);                  // frame of a batch (0 otherwise)
+    select_frame(dst, blockIdx.x);
+    out24 += (size_t)blockIdx.x * tabStride;
     float A[12], B[12], T_ds[12], T_sd[12];
     for (int i = 0; i < 12; ++i) { A[i] = dst.T_mc[i]; B[i] = src.T_cm[i]; }
     se3_mul(A, B, T_ds);
@@ -269,7 +288,7 @@ int gn_ne_self_any(int red, const float *d_sites, int nSites, int fullDims, int 
 }
 int gn_ne_inter_any(int red, const float *d_sites, int nSites, int fullDims, int redDims, Model *src, Model *dst,
                     const float *d_A, const int *d_map, float *d_T_scratch24, float *d_result, hipStream_t st) {
-    hipLaunchKernelGGL(pair_transform_kernel, dim3(1), dim3(64), 0, st, src->v, dst->v, d_T_scratch24);
+    hipLaunchKernelGGL(pair_transform_kernel, dim3(cur_batch().n), dim3(64), 0, st, src->v, dst->v, d_T_scratch24, cur_batch().tab);
     if (red == 1) return launch_inter_dev<1>(d_sites, nSites, fullDims, redDims, d_T_scratch24, src, dst, d_A, nullptr, d_result, st);
     if (red == 2) return launch_inter_dev<2>(d_sites, nSites, fullDims, redDims, d_T_scratch24, src, dst, nullptr, d_map, d_result, st);
     return launch_inter_dev<0>(d_sites, nSites, fullDims, fullDims, d_T_scratch24, src, dst, nullptr, nullptr, d_result, st);

@@ -9,6 +9,27 @@ namespace dartk {
 
 static constexpr int NE_BLOCK = 128;   // lanes (= points per tile) of every normal-equation workgroup
 
+// Independent frames processed side by side by one launch (grid.y = frame), dartk_optimize_poses_batch. Strides are what lies
+// between two frames in the respective arrays; partial-system slabs need none (frame f's slabs follow frame f-1's:
+// (blockIdx.y * gridDim.x + blockIdx.x) * S). The launchers read the calling thread's current batch (one frame, all strides 0,
+// unless a batched loop has set it), so every operator-API entry point keeps its single-frame meaning.
+struct FrameBatch {
+    int n;                  // frames
+    int counts;             // ints per frame in the counter arrays (association / prediction counts)
+    int sys;                // floats per frame in the table of reduced packed systems
+    int tab;                // floats per frame in the table of observation-SDF poses and pair transforms
+    size_t vert;            // float4 per frame in the observation vertex / normal maps
+    size_t pred;            // float4 per frame in the prediction map
+    size_t trace;           // floats per frame in the ray-cast trace buffer
+    size_t pts;             // records per frame in every model's association list
+};
+FrameBatch &cur_batch();    // host: the calling thread's current batch
+struct BatchScope {         // sets the current batch for a scope
+    FrameBatch saved;
+    explicit BatchScope(const FrameBatch &b) : saved(cur_batch()) { cur_batch() = b; }
+    ~BatchScope() { cur_batch() = saved; }
+};
+
 int ensure_partials(Workspace *w, size_t floats);
 int noalloc_scratch(float **out);      // dartk_obs2mod.hip: device address of the no-allocation entry point's scratch array
 int get_multi_args_buffer(void **d_ptr, size_t bytes);

@@ -43,8 +43,11 @@ __device__ __forceinline__ RayGeom ray_in_frame(const float *T_fc, int x, int y,
 }
 
 __global__ void __launch_bounds__(256)
-raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int height, ModelView m,
-                     float2 *__restrict__ trace /*[nSdfs][width*height]*/, float levelSet) {
+raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int height, ModelView m_in,
+                     float2 *__restrict__ trace /*[nSdfs][width*height]*/, float levelSet, FrameBatch fb) {
+    ModelView m = m_in;
+    select_frame(m, blockIdx.y);                    // frame of a batch (0 otherwise)
+    trace += (size_t)blockIdx.y * (fb.trace >> 1);
     const int tilesX = (width + 7) >> 3, tilesY = (height + 7) >> 3;
     const int nTiles = tilesX * tilesY;
     const int lane = threadIdx.x & 63;
@@ -275,8 +278,12 @@ static_assert(sizeof(ReplayMultiArgs) <= 3584, "ReplayMultiArgs is passed by val
 __global__ void __launch_bounds__(256)
 raycast_replay_multi_kernel(float flx, float fly, float ppx, float ppy, int width, int height, ReplayMultiArgs a,
                             const float *__restrict__ rayBuf, float4 *__restrict__ prediction, const float4 *__restrict__ obs, int ow,
-                            int oh) {
+                            int oh, FrameBatch fb) {
     __shared__ float sT[RC_REPLAY_SDFS * 24];
+    const int frame = blockIdx.y;                   // frame of a batch (0 otherwise)
+    rayBuf += (size_t)frame * fb.trace;
+    prediction += (size_t)frame * fb.pred;
+    obs += (size_t)frame * fb.vert;
     const int nPix = width * height;
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = index < nPix;
@@ -284,7 +291,8 @@ raycast_replay_multi_kernel(float flx, float fly, float ppx, float ppy, int widt
     float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) { pr = prediction[index]; pr.z = 0; pr.w = -1; }    // model 0 starts the map (x, y keep what the map held, as there)
     for (int mi = 0; mi < a.n; ++mi) {
-        const ModelView &m = a.m[mi];
+        ModelView m = a.m[mi];
+        select_frame(m, frame);
         const float2 *trace = reinterpret_cast<const float2 *>(rayBuf + a.off[mi]);
         float closestT = 10000;
         for (int s0 = 0; s0 < m.nSdfs; s0 += RC_REPLAY_SDFS) {
@@ -307,13 +315,13 @@ raycast_replay_multi_kernel(float flx, float fly, float ppx, float ppy, int widt
 static int launch_raycast_trace(float flx, float fly, float ppx, float ppy, int width, int height, const ModelView &m, float levelSet,
                                 Workspace *ws, hipStream_t st, size_t bufOffset = 0) {
     const size_t nPix = (size_t)width * height;
-    int rc = ensure_ray_buf(ws, bufOffset + 2 * nPix * (size_t)m.nSdfs);     // (callers with an offset have sized the buffer already)
+    int rc = cur_batch().n > 1 ? DARTK_OK : ensure_ray_buf(ws, bufOffset + 2 * nPix * (size_t)m.nSdfs);     // (callers with an offset / a batch have sized the buffer already)
     if (rc) return rc;
     const long long tasks = (long long)((width + 7) / 8) * ((height + 7) / 8) * m.nSdfs;
     DARTK_REQUIRE(tasks < (1ll << 31), "ray-cast of %dx%d against %d SDFs exceeds the launch limits", width, height, m.nSdfs);
     ProfScope ps(DARTK_PROF_RAYCAST, st);
-    hipLaunchKernelGGL(raycast_trace_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height, m,
-                       (float2 *)(ws->rayBuf + bufOffset), levelSet);
+    hipLaunchKernelGGL(raycast_trace_kernel, dim3((unsigned)((tasks + 3) / 4), cur_batch().n), dim3(256), 0, st, flx, fly, ppx, ppy, width, height, m,
+                       (float2 *)(ws->rayBuf + bufOffset), levelSet, cur_batch());
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
@@ -344,7 +352,10 @@ __global__ void cull_unobservable_kernel(float4 *__restrict__ pred, int pw, int 
 }
 
 // gpu_splatObsSdf, modToObs.cu:403-441
-__global__ void splat_obs_sdf_kernel(const float4 *__restrict__ vert, int width, int height, ModelView m, float focalLength) {
+__global__ void splat_obs_sdf_kernel(const float4 *__restrict__ vert, int width, int height, ModelView m_in, float focalLength, FrameBatch fb) {
+    ModelView m = m_in;
+    select_frame(m, blockIdx.y);                    // frame of a batch (0 otherwise)
+    vert += (size_t)blockIdx.y * fb.vert;
     const int nVox = m.obs.dimx * m.obs.dimy * m.obs.dimz;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nVox) return;
@@ -400,8 +411,10 @@ dt_pass_x_kernel(const float *__restrict__ in, float *__restrict__ out, int len,
 static constexpr int DT_QCHUNK = 16;
 __global__ void __launch_bounds__(256)
 dt_pass_strided_kernel(const float *__restrict__ in, float *__restrict__ out, int len, int stride, int width, int nOuter,
-                       int outerStride, int takeSqrt) {
+                       int outerStride, int takeSqrt, size_t volumeStride) {
     extern __shared__ float lds[];      // [len][64]
+    in += (size_t)blockIdx.y * volumeStride;        // volume blockIdx.y of a batch of equally sized volumes
+    out += (size_t)blockIdx.y * volumeStride;
     const int tilesX = (width + 63) / 64;
     const int qChunks = (len + DT_QCHUNK - 1) / DT_QCHUNK;
     const int qc = blockIdx.x % qChunks;
@@ -432,22 +445,24 @@ dt_pass_strided_kernel(const float *__restrict__ in, float *__restrict__ out, in
         if (q0 + k < len) out[base + (size_t)(q0 + k) * stride] = takeSqrt ? sqrtf(r[k]) : r[k];
 }
 
-int launch_distance_transform_3d(float *in, float *out, int width, int height, int depth, int takeSqrt, hipStream_t st) {
+// nVolumes equally sized volumes, back to back, are transformed by the same three launches
+int launch_distance_transform_3d(float *in, float *out, int width, int height, int depth, int takeSqrt, hipStream_t st, int nVolumes = 1) {
     DARTK_REQUIRE(width >= 1 && height >= 1 && depth >= 1 && width <= 512 && height <= 512 && depth <= 512,
                   "distance transform dimensions must be in [1,512], got %dx%dx%d", width, height, depth);
+    const size_t volume = (size_t)width * height * depth;
     // x: in -> out ; z: out -> in ; y: in -> out (sqrt)   (distance_transforms.cu:440-456)
     {
-        const int nLines = height * depth;
+        const int nLines = height * depth * nVolumes;
         const int lpb = 256 / width > 0 ? 256 / width : 1;
         hipLaunchKernelGGL(dt_pass_x_kernel, dim3((nLines + lpb - 1) / lpb), dim3(256), sizeof(float) * (size_t)(lpb * width), st,
                            in, out, width, nLines, 0);
     }
     const int tilesX = (width + 63) / 64;
     const int qcZ = (depth + DT_QCHUNK - 1) / DT_QCHUNK, qcY = (height + DT_QCHUNK - 1) / DT_QCHUNK;
-    hipLaunchKernelGGL(dt_pass_strided_kernel, dim3(tilesX * height * qcZ), dim3(256), sizeof(float) * 64 * (size_t)depth, st,
-                       out, in, depth, width * height, width, height, width, 0);
-    hipLaunchKernelGGL(dt_pass_strided_kernel, dim3(tilesX * depth * qcY), dim3(256), sizeof(float) * 64 * (size_t)height, st,
-                       in, out, height, width, width, depth, width * height, takeSqrt);
+    hipLaunchKernelGGL(dt_pass_strided_kernel, dim3(tilesX * height * qcZ, nVolumes), dim3(256), sizeof(float) * 64 * (size_t)depth, st,
+                       out, in, depth, width * height, width, height, width, 0, volume);
+    hipLaunchKernelGGL(dt_pass_strided_kernel, dim3(tilesX * depth * qcY, nVolumes), dim3(256), sizeof(float) * 64 * (size_t)height, st,
+                       in, out, height, width, width, depth, width * height, takeSqrt, volume);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
@@ -485,10 +500,15 @@ struct ReplayArgs {            // REPLAY variant: the prediction is formed in th
 
 template <int PPT, int RED, bool TRUNC, bool REPLAY = false>
 __global__ void __launch_bounds__(NE_BLOCK)
-ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, ModelView m, const float *__restrict__ T_gc_in,
+ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, ModelView m_in, const float *__restrict__ T_gc_in,
                   float truncationDist, int redDims, const float *__restrict__ dtheta_dalpha, const int *__restrict__ mapping,
-                  float *__restrict__ slabs, int *__restrict__ numPredictions, ReplayArgs ra) {
+                  float *__restrict__ slabs, int *__restrict__ numPredictions, ReplayArgs ra, FrameBatch fb, int tgcStride) {
     extern __shared__ float lds[];
+    ModelView m = m_in;
+    select_frame(m, blockIdx.y);                    // frame of a batch (0 otherwise)
+    pred += (size_t)blockIdx.y * fb.pred;
+    T_gc_in += (size_t)blockIdx.y * tgcStride;
+    numPredictions += (size_t)blockIdx.y * fb.counts;
     const int fullDims = 6 + m.nJoints;
     const int d = RED ? redDims : fullDims;
     const int ld = row_len(d, false);
@@ -567,7 +587,7 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
         myCount += nActive;
         __syncthreads();
     }
-    acc.store(slabs + (size_t)blockIdx.x * sys_size(d), sys_size(d));
+    acc.store(slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * sys_size(d), sys_size(d));
     if (threadIdx.x == 0 && myCount) atomicAdd(numPredictions, myCount);
 }
 
@@ -589,13 +609,15 @@ static int launch_ne_mod2obs_kernel(int fullDims, int redDims, const float *d_pr
     const size_t ldsBytes = ne_mod2obs_lds_bytes(m, d, RED);
     DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
     const float4 *pred = reinterpret_cast<const float4 *>(d_pred);
+    const FrameBatch fb = cur_batch();
+    const int tgcStride = (d_T_gc == m.T_mc) ? m.poseStride : fb.tab;      // the model's own (per-frame) T_mc, or an entry of the per-frame table
 #define DARTK_LAUNCH_M2O(PPT_)                                                                                  \
     do {                                                                                                        \
         auto kfn = ne_mod2obs_kernel<PPT_, RED, TRUNC>;                                                         \
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
-        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, pred, nPix, m.modelId, m, d_T_gc, trunc,     \
-                           redDims, d_A, d_map, slabs, d_num, ReplayArgs{});                                    \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks, fb.n), dim3(NE_BLOCK), ldsBytes, st, pred, nPix, m.modelId, m, d_T_gc, trunc, \
+                           redDims, d_A, d_map, slabs, d_num, ReplayArgs{}, fb, tgcStride);                     \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_M2O(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_M2O(6);
@@ -621,8 +643,9 @@ static int launch_ne_mod2obs(int fullDims, int redDims, const float *d_pred, int
     if (rc) return rc;
     const int nPix = width * height;
     const int nTiles = (nPix + NE_BLOCK - 1) / NE_BLOCK;
-    const int nBlocks = nTiles < kMaxPartialBlocks ? nTiles : kMaxPartialBlocks;
-    rc = ensure_partials(ws, (size_t)nBlocks * S);
+    const int cap = cur_batch().n > 1 ? 128 : kMaxPartialBlocks;    // a batch fills the chip with its frames
+    const int nBlocks = nTiles < cap ? nTiles : cap;
+    rc = ensure_partials(ws, (size_t)cur_batch().n * nBlocks * S);
     if (rc) return rc;
     if (zeroCounter) DARTK_HIP(hipMemsetAsync(d_num, 0, sizeof(int), st));
     rc = launch_ne_mod2obs_kernel<RED, TRUNC>(fullDims, redDims, d_pred, width, height, m, d_T_gc, trunc, d_A, d_map,
@@ -662,7 +685,7 @@ int gn_launch_raycast_trace_at(float flx, float fly, float ppx, float ppy, int w
     Workspace *ws;
     int rc = get_workspace(&ws);
     if (rc) return rc;
-    DARTK_REQUIRE(bufOffset + 2 * (size_t)width * height * m.nSdfs <= ws->rayFloats, "trace buffer was not reserved");
+    DARTK_REQUIRE((cur_batch().n - 1) * cur_batch().trace + bufOffset + 2 * (size_t)width * height * m.nSdfs <= ws->rayFloats, "trace buffer was not reserved");
     return launch_raycast_trace(flx, fly, ppx, ppy, width, height, m, 0.0f, ws, st, bufOffset);
 }
 int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float ppy, int width, int height, int nModels,
@@ -678,8 +701,8 @@ int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float p
     for (int m = 0; m < nModels; ++m) { a.m[m] = mods[m]->v; a.off[m] = bufOffsets[m]; }
     const size_t nPix = (size_t)width * height;
     ProfScope ps2(DARTK_PROF_RAYCAST_REPLAY, st);
-    hipLaunchKernelGGL(raycast_replay_multi_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height,
-                       a, (const float *)ws->rayBuf, (float4 *)d_prediction, (const float4 *)d_obs, ow, oh);
+    hipLaunchKernelGGL(raycast_replay_multi_kernel, dim3((unsigned)((nPix + 255) / 256), cur_batch().n), dim3(256), 0, st, flx, fly, ppx, ppy, width, height,
+                       a, (const float *)ws->rayBuf, (float4 *)d_prediction, (const float4 *)d_obs, ow, oh, cur_batch());
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
@@ -726,7 +749,7 @@ int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
         hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_prediction, nPix, m.modelId, m, d_T_gc, 0.f, \
-                           d, nullptr, nullptr, slabs, d_num, ra);                                              \
+                           d, nullptr, nullptr, slabs, d_num, ra, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0}, 0);                   \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_RM2O(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_RM2O(6);
@@ -744,11 +767,13 @@ int gn_launch_cull(float *d_pred, int pw, int ph, const float *d_obs, int ow, in
 int gn_obs_sdf_build(const float *d_vert, int width, int height, Model *mod, float focalLength, hipStream_t st) {
     const ModelView &m = mod->v;
     const int n = (int)mod->obsVoxels;
-    hipLaunchKernelGGL(splat_obs_sdf_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float4 *)d_vert, width, height, m, focalLength);
+    const FrameBatch fb = cur_batch();              // a batch: the frames' observation SDFs lie obsStride (= n) floats apart
+    DARTK_REQUIRE(fb.n == 1 || m.obsStride == n, "batched observation SDFs must be contiguous");
+    hipLaunchKernelGGL(splat_obs_sdf_kernel, dim3((n + 255) / 256, fb.n), dim3(256), 0, st, (const float4 *)d_vert, width, height, m, focalLength, fb);
     DARTK_HIP(hipGetLastError());
-    int rc = launch_distance_transform_3d(m.obsData, mod->dtTmp, m.obs.dimx, m.obs.dimy, m.obs.dimz, 1, st);
+    int rc = launch_distance_transform_3d(m.obsData, mod->dtTmp, m.obs.dimx, m.obs.dimy, m.obs.dimz, 1, st, fb.n);
     if (rc) return rc;
-    DARTK_HIP(hipMemcpyAsync(m.obsData, mod->dtTmp, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, st));  // optimizer.cpp:215
+    DARTK_HIP(hipMemcpyAsync(m.obsData, mod->dtTmp, sizeof(float) * (size_t)n * fb.n, hipMemcpyDeviceToDevice, st));  // optimizer.cpp:215
     return DARTK_OK;
 }
 

@@ -25,6 +25,9 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+static thread_local FrameBatch t_batch = {1, 0, 0, 0, 0, 0, 0, 0};
+FrameBatch &cur_batch() { return t_batch; }
+
 static Workspace g_ws[16];
 static bool g_ws_ready[16] = {false};
 
@@ -105,8 +108,11 @@ static constexpr int kReduceSegs = 32;
 
 __global__ void __launch_bounds__(kReduceOuts * kReduceSegs)
 reduce_slabs_kernel(const float *__restrict__ slabs, int nBlocks, int S, float *__restrict__ result, int keep,
-                    const int *__restrict__ count, int minCount) {
+                    const int *__restrict__ count, int minCount, FrameBatch fb) {
     __shared__ double part[kReduceSegs][kReduceOuts + 1];
+    slabs += (size_t)blockIdx.y * nBlocks * S;      // frame blockIdx.y of a batch (0 otherwise)
+    result += (size_t)blockIdx.y * fb.sys;
+    if (count) count += (size_t)blockIdx.y * fb.counts;
     const int col = threadIdx.x % kReduceOuts, seg = threadIdx.x / kReduceOuts;
     const int o = blockIdx.x * kReduceOuts + col;
     if (count) keep = *count > minCount;
@@ -132,16 +138,16 @@ reduce_slabs_kernel(const float *__restrict__ slabs, int nBlocks, int S, float *
 }
 
 int launch_reduce_slabs(const float *slabs, int nBlocks, int S, float *result, int keep, hipStream_t stream) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((S + kReduceOuts - 1) / kReduceOuts), dim3(kReduceOuts * kReduceSegs), 0,
-                       stream, slabs, nBlocks, S, result, keep, (const int *)nullptr, 0);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((S + kReduceOuts - 1) / kReduceOuts, cur_batch().n), dim3(kReduceOuts * kReduceSegs), 0,
+                       stream, slabs, nBlocks, S, result, keep, (const int *)nullptr, 0, cur_batch());
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
 
 int launch_reduce_slabs_gated(const float *slabs, int nBlocks, int S, float *result, const int *d_count, int minCount,
                               hipStream_t stream) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((S + kReduceOuts - 1) / kReduceOuts), dim3(kReduceOuts * kReduceSegs), 0,
-                       stream, slabs, nBlocks, S, result, 0, d_count, minCount);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((S + kReduceOuts - 1) / kReduceOuts, cur_batch().n), dim3(kReduceOuts * kReduceSegs), 0,
+                       stream, slabs, nBlocks, S, result, 0, d_count, minCount, cur_batch());
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }

@@ -35,7 +35,32 @@ struct MultiSolveArgs {
     float *iterInfo;        // [numIterations][nModels][8] or null
     float *firstSystem;     // [D*D + D] or null
     MultiSolveModel m[DARTK_MAX_MODELS];
+    // batches of independent frames (workgroup = frame): what lies between two frames in the tables the pointers above
+    // name (systems, counts: FrameBatch; reduced articulations; iteration summaries). All 0 for the single-frame loop.
+    FrameBatch fb;
+    int redStride;
+    size_t infoStride;
+    // batch only: the caller's pose arrays, read before the first iteration / written after the last (iteration == -1 / -2)
+    float *T_mcs;           // [frames][nModels][12]
 };
+
+// projection of the reduced articulation in ra[] (LDS) to the full joint vector (pose.cpp:66-73, 91-97) and forward
+// kinematics (Tracker::updatePose) of one model; one wave
+__device__ __forceinline__ void project_and_fk(const MultiSolveModel &m, const ModelView &v, const float *ra, float *sT) {
+    const int lane = threadIdx.x;
+    if (lane < v.nJoints) {       // lane f writes joint f and is the lane that reads it back in fk_wave
+        float full;
+        if (m.redType == 0) full = ra[lane];
+        else if (m.redType == 2) full = ra[m.map[lane]];
+        else {
+            full = m.b[lane];
+            for (int r = 0; r < m.redArt; ++r) full = full + ra[r] * m.A[r + lane * m.redArt];      // pose.cpp:66-73
+        }
+        v.joints[lane] = full;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fk_wave(v, 0, sT);
+}
 
 __device__ __forceinline__ void wave_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -59,6 +84,8 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration) {
     extern __shared__ float lds[];
     const MultiSolveArgs &a = *ap;
     const int lane = threadIdx.x;
+    const int frame = blockIdx.x;                   // frame of a batch (0 otherwise)
+    const size_t so = (size_t)frame * a.fb.sys, co = (size_t)frame * a.fb.counts;
     const int D = a.D;
     const int ldU = (D + 1) | 1;
     float *U = lds;                     // [D][ldU] upper triangle of the global system
@@ -67,6 +94,29 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration) {
     float *eJ = J + D * ldU;            // [D]
     float *ra = eJ + D;                 // reduced articulation of the model being updated [<= 64]
     float *sT = ra + 64;                // forward-kinematics scratch
+    if (iteration < 0) {        // batch only: import (-1) / export (-2) the caller's poses
+        for (int mi = 0; mi < a.nModels; ++mi) {
+            const MultiSolveModel &m = a.m[mi];
+            ModelView v = m.v;
+            select_frame(v, frame);
+            float *T_io = a.T_mcs + ((size_t)frame * a.nModels + mi) * 12;
+            if (iteration == -2) {
+                if (lane < 12) T_io[lane] = v.T_mc[lane];
+                continue;
+            }
+            if (lane == 0) {
+                float T[12], Tinv[12];
+                for (int i = 0; i < 12; ++i) T[i] = T_io[i];
+                se3_invert(T, Tinv);
+                for (int i = 0; i < 12; ++i) { v.T_mc[i] = T[i]; v.T_cm[i] = Tinv[i]; }
+            }
+            if (lane < m.redArt) ra[lane] = m.redArtPtr[(size_t)frame * a.redStride + lane];
+            wave_sync_lds();
+            project_and_fk(m, v, ra, sT);
+            wave_sync_lds();
+        }
+        return;
+    }
     for (int i = lane; i < D * ldU; i += 64) U[i] = 0.0f;
     for (int i = lane; i < D; i += 64) bv[i] = 0.0f;
     wave_sync_lds();
@@ -77,14 +127,14 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration) {
         for (int i = lane; i < dims; i += 64) eJ[i] = 0.0f;
         wave_sync_lds();
         float eA = 0.0f, eB = 0.0f, eI = 0.0f;
-        if (m.sysA) { unpack_block(J, ldU, eJ, m.sysA, a.lambdaA, dims, 0); eA = a.lambdaA * m.sysA[sys_size(dims) - 1]; }
-        if (m.sysB) { unpack_block(J, ldU, eJ, m.sysB, a.lambdaB, dims, 0); eB = a.lambdaB * m.sysB[sys_size(dims) - 1]; }
-        if (m.sysC) { unpack_block(J, ldU, eJ, m.sysC, m.lamSelf, dims, 6); eI = m.lamSelf * m.sysC[sys_size(dims - 6) - 1]; }
+        if (m.sysA) { unpack_block(J, ldU, eJ, m.sysA + so, a.lambdaA, dims, 0); eA = a.lambdaA * m.sysA[so + sys_size(dims) - 1]; }
+        if (m.sysB) { unpack_block(J, ldU, eJ, m.sysB + so, a.lambdaB, dims, 0); eB = a.lambdaB * m.sysB[so + sys_size(dims) - 1]; }
+        if (m.sysC) { unpack_block(J, ldU, eJ, m.sysC + so, m.lamSelf, dims, 6); eI = m.lamSelf * m.sysC[so + sys_size(dims - 6) - 1]; }
         for (int d = 0; d < a.nModels; ++d)
-            if (m.sysI[d]) { unpack_block(J, ldU, eJ, m.sysI[d], m.lamI[d], dims, 0); eI = m.lamI[d] * m.sysI[d][sys_size(dims) - 1]; }
+            if (m.sysI[d]) { unpack_block(J, ldU, eJ, m.sysI[d] + so, m.lamI[d], dims, 0); eI = m.lamI[d] * m.sysI[d][so + sys_size(dims) - 1]; }
         if (a.iterInfo && lane == 0) {      // e is assigned per term, the last one stays (SURVEY A-8)
-            float *r = a.iterInfo + ((size_t)iteration * a.nModels + mi) * 8;
-            r[0] = eA; r[1] = eB; r[2] = eI; r[3] = m.countA ? (float)*m.countA : 0.0f; r[4] = m.countB ? (float)*m.countB : 0.0f;
+            float *r = a.iterInfo + (size_t)frame * a.infoStride + ((size_t)iteration * a.nModels + mi) * 8;
+            r[0] = eA; r[1] = eB; r[2] = eI; r[3] = m.countA ? (float)m.countA[co] : 0.0f; r[4] = m.countB ? (float)m.countB[co] : 0.0f;
             r[5] = r[6] = r[7] = 0.0f;
         }
         // regularisation, LM scaling (optimizer.cpp:695-700), then the upper triangle goes into the global system (:707-713)
@@ -102,7 +152,7 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration) {
         for (int i = lane; i < dims; i += 64) bv[off + i] = eJ[i];
         wave_sync_lds();
     }
-    if (a.firstSystem && iteration == 0) {
+    if (a.firstSystem && iteration == 0 && frame == 0) {
         for (int idx = lane; idx < D * D; idx += 64) a.firstSystem[idx] = U[(idx / D) * ldU + (idx % D)];
         for (int i = lane; i < D; i += 64) a.firstSystem[D * D + i] = bv[i];
     }
@@ -127,34 +177,26 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration) {
     for (int mi = 0; mi < a.nModels; ++mi) {
         const MultiSolveModel &m = a.m[mi];
         const int off = m.off;
+        ModelView v = m.v;
+        select_frame(v, frame);
         if (lane == 0) {
             float t6[6], dT[12], T[12], Tn[12], Tinv[12];
             for (int i = 0; i < 6; ++i) t6[i] = bv[off + i];
             se3_exp(t6, dT);
-            for (int i = 0; i < 12; ++i) T[i] = m.v.T_mc[i];
+            for (int i = 0; i < 12; ++i) T[i] = v.T_mc[i];
             se3_mul(dT, T, Tn);
             se3_invert(Tn, Tinv);
-            for (int i = 0; i < 12; ++i) { m.v.T_mc[i] = Tn[i]; m.v.T_cm[i] = Tinv[i]; }
+            for (int i = 0; i < 12; ++i) { v.T_mc[i] = Tn[i]; v.T_cm[i] = Tinv[i]; }
         }
         if (lane < m.redArt) {
-            const float v = m.redArtPtr[lane] + bv[off + 6 + lane];
-            const float c = fminf(fmaxf(m.redMin[lane], v), m.redMax[lane]);
-            m.redArtPtr[lane] = c;
+            float *rp = m.redArtPtr + (size_t)frame * a.redStride;
+            const float val = rp[lane] + bv[off + 6 + lane];
+            const float c = fminf(fmaxf(m.redMin[lane], val), m.redMax[lane]);
+            rp[lane] = c;
             ra[lane] = c;
         }
         wave_sync_lds();
-        if (lane < m.v.nJoints) {       // lane f writes joint f and is the lane that reads it back in fk_wave
-            float full;
-            if (m.redType == 0) full = ra[lane];
-            else if (m.redType == 2) full = ra[m.map[lane]];
-            else {
-                full = m.b[lane];
-                for (int r = 0; r < m.redArt; ++r) full = full + ra[r] * m.A[r + lane * m.redArt];      // pose.cpp:66-73
-            }
-            m.v.joints[lane] = full;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        fk_wave(m.v, 0, sT);
+        project_and_fk(m, v, ra, sT);
         wave_sync_lds();
     }
 }
@@ -176,22 +218,15 @@ static int multi_scratch(size_t bytes, void **out) {
     return DARTK_OK;
 }
 
-}  // namespace dartk
-
-using namespace dartk;
-
-extern "C" {
-
-int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *mm, const float *d_vert, const float *d_norm,
-                         int width, int height, float *d_prediction, float *d_iterInfo, float *d_firstSystem, void *stream) {
-    DARTK_REQUIRE(o && mm && d_vert && d_norm, "dartk_optimize_poses: null argument");
+// One call of Optimizer::optimizePoses for nFrames independent frames side by side (nFrames == 1 and d_T_mcs == nullptr: the
+// classic single-frame call on the model handles' own poses). Every launch covers all frames (grid.y = frame; the solve: one
+// wave per frame); the frames share the models' SDFs and tables and differ in observation maps, poses and observation SDFs.
+static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_model *mm, int nFrames, const float *d_vert,
+                               const float *d_norm, int width, int height, float *d_prediction, float *d_T_mcs, float *d_redArtBatch,
+                               float *d_iterInfo, float *d_firstSystem, hipStream_t st) {
     const int n = o->nModels;
-    DARTK_REQUIRE(n >= 1 && n <= DARTK_MAX_MODELS, "nModels %d out of range [1,%d]", n, DARTK_MAX_MODELS);
-    DARTK_REQUIRE(width > 0 && height > 0 && (long long)width * height < (1ll << 31), "bad map size %dx%d", width, height);
-    DARTK_REQUIRE(o->numIterations >= 0, "negative iteration count");
+    const bool batch = d_T_mcs != nullptr;
     const bool useA = o->lambdaObsToMod > 0, useB = o->lambdaModToObs > 0;
-    if (useB) DARTK_REQUIRE(d_prediction && o->predWidth > 0 && o->predHeight > 0, "mod->obs term needs a prediction buffer");
-    hipStream_t st = as_stream(stream);
     Workspace *ws;
     int rc = get_workspace(&ws);
     if (rc) return rc;
@@ -199,8 +234,11 @@ int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *
     static thread_local MultiSolveArgs h;
     memset(&h, 0, sizeof(h));
     Model *mods[DARTK_MAX_MODELS];
-    int D = 0, maxFrames = 1;
-    size_t tableFloats = 0, sysFloats = 0;
+    static thread_local Model views[DARTK_MAX_MODELS];       // batch: the handles' static tables with per-frame pose / obs-SDF arrays
+    int D = 0, maxFrames = 1, redTotal = 0, redOff[DARTK_MAX_MODELS];
+    size_t tableFloats = 0, sysFloats = 0, poseFloats = 0, obsFloats = 0;
+    size_t poseOff[DARTK_MAX_MODELS], obsOff[DARTK_MAX_MODELS];
+    const int nPix = width * height, nPred = o->predWidth * o->predHeight;
     for (int m = 0; m < n; ++m) {
         mods[m] = reinterpret_cast<Model *>(mm[m].model);
         DARTK_REQUIRE(mods[m], "dartk_optimize_poses: null model %d", m);
@@ -210,48 +248,90 @@ int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *
         DARTK_REQUIRE(redArt >= 0 && redArt <= v.nJoints, "model %d: %d reduced dimensions for %d joints", m, redArt, v.nJoints);
         DARTK_REQUIRE(mm[m].redType != 1 || mm[m].d_A, "model %d: linear reduction without its matrix", m);
         DARTK_REQUIRE(mm[m].redType != 2 || mm[m].d_map, "model %d: parameter map without its mapping", m);
-        DARTK_REQUIRE(redArt == 0 || (mm[m].d_redArt && mm[m].h_redMin && mm[m].h_redMax), "model %d: reduced articulation / limits missing", m);
-        DARTK_REQUIRE(!useA || mm[m].d_pts, "model %d: association buffer missing", m);
+        DARTK_REQUIRE(redArt == 0 || ((batch || mm[m].d_redArt) && mm[m].h_redMin && mm[m].h_redMax), "model %d: reduced articulation / limits missing", m);
+        DARTK_REQUIRE(!useA || batch || mm[m].d_pts, "model %d: association buffer missing", m);
         DARTK_REQUIRE(!useB || mods[m]->obsVoxels > 0, "model %d has no observation SDF", m);
         h.m[m].redType = mm[m].redType; h.m[m].redArt = redArt; h.m[m].dims = 6 + redArt; h.m[m].off = D;
         D += 6 + redArt;
+        redOff[m] = redTotal; redTotal += redArt;
         if (v.nFrames > maxFrames) maxFrames = v.nFrames;
-        tableFloats += (size_t)v.nJoints + 2 * (size_t)redArt + 12 + 24;     // b | min | max | T_obs | pair transform
+        tableFloats += (size_t)v.nJoints + 2 * (size_t)redArt;              // b | min | max (shared by the frames)
         sysFloats += (size_t)(2 + n) * sys_size(6 + redArt) + sys_size(redArt > 0 ? redArt : 1);
+        poseOff[m] = poseFloats; poseFloats += 24 + 24 * (size_t)v.nFrames + (size_t)(v.nJoints > 0 ? v.nJoints : 1);
+        obsOff[m] = obsFloats; obsFloats += mods[m]->obsVoxels;
     }
     DARTK_REQUIRE(D <= 64, "global system dimension %d exceeds 64 (one lane per unknown in the solve)", D);
+    // per-frame tables: observation-SDF poses [n][12] and pair transforms [n][24]; counters [countA | countB]
+    const int tabStride = 36 * n;
+    FrameBatch fb = {nFrames, DARTK_MAX_MODELS, (int)sysFloats, tabStride, (size_t)nPix, (size_t)nPred, 0, (size_t)nPix};
+    size_t traceOff[DARTK_MAX_MODELS], traceFloats = 0;         // every model's slice of a frame's ray-cast trace buffer
+    for (int m = 0; m < n; ++m) { traceOff[m] = traceFloats; traceFloats += 2 * (size_t)nPred * mods[m]->v.nSdfs; }
+    fb.trace = traceFloats;
+    if (!batch) fb = FrameBatch{1, 0, 0, 0, 0, 0, 0, 0};
+
+    // one allocation: [args | countA | countB | shared tables | per-frame tables | per-frame systems] and, for a batch,
+    // [poses | observation SDFs | distance-transform scratch | prediction maps | association lists]
     const size_t argBytes = (sizeof(MultiSolveArgs) + 255) / 256 * 256;
-    const size_t total = argBytes + sizeof(float) * (tableFloats + sysFloats) + sizeof(int) * 2 * DARTK_MAX_MODELS + 256;
+    const size_t cntInts = 2 * (size_t)DARTK_MAX_MODELS * nFrames;
+    size_t floatsSmall = tableFloats + (size_t)nFrames * (tabStride + sysFloats);
+    size_t total = argBytes + sizeof(int) * cntInts + sizeof(float) * floatsSmall + 1024;
+    size_t o_pose = 0, o_obs = 0, o_tmp = 0, o_pred = 0, o_pts = 0;
+    if (batch) {
+        auto take = [&](size_t bytes) { size_t at = (total + 255) / 256 * 256; total = at + bytes; return at; };
+        o_pose = take(sizeof(float) * poseFloats * nFrames);
+        o_obs = take(sizeof(float) * obsFloats * nFrames);
+        o_tmp = take(sizeof(float) * obsFloats * nFrames);
+        o_pred = take(sizeof(float) * 4 * (size_t)nPred * nFrames);
+        o_pts = useA ? take(sizeof(dartk_da_point) * (size_t)nPix * nFrames * n) : 0;
+    }
     void *base = nullptr;
     rc = multi_scratch(total, &base);
     if (rc) return rc;
     MultiSolveArgs *d_args = reinterpret_cast<MultiSolveArgs *>(base);
     int *d_countA = reinterpret_cast<int *>((char *)base + argBytes);
-    int *d_countB = d_countA + DARTK_MAX_MODELS;
-    float *fl = reinterpret_cast<float *>(d_countB + DARTK_MAX_MODELS);
+    int *d_countB = d_countA + (size_t)DARTK_MAX_MODELS * nFrames;
+    float *fl = reinterpret_cast<float *>(d_countB + (size_t)DARTK_MAX_MODELS * nFrames);
+    if (batch) {
+        for (int m = 0; m < n; ++m) {       // model m's frame records lie back to back: [frame][T_mc|T_cm|T_mf|T_fm|joints]
+            views[m] = *mods[m];
+            ModelView &v = views[m].v;
+            const int nF = v.nFrames;
+            const size_t rec = 24 + 24 * (size_t)nF + (size_t)(v.nJoints > 0 ? v.nJoints : 1);
+            float *p = reinterpret_cast<float *>((char *)base + o_pose) + poseOff[m] * nFrames;
+            v.T_mc = p; v.T_cm = p + 12; v.T_mf = p + 24; v.T_fm = p + 24 + 12 * nF; v.joints = p + 24 + 24 * nF;
+            v.poseStride = (int)rec;
+            v.obsData = reinterpret_cast<float *>((char *)base + o_obs) + obsOff[m] * nFrames;
+            v.obsStride = (int)mods[m]->obsVoxels;
+            views[m].dtTmp = reinterpret_cast<float *>((char *)base + o_tmp) + obsOff[m] * nFrames;
+            mods[m] = &views[m];
+        }
+        d_prediction = reinterpret_cast<float *>((char *)base + o_pred);
+    }
     std::vector<float> tables;
     float *T_obs[DARTK_MAX_MODELS], *T_pair[DARTK_MAX_MODELS];
     float *sysA[DARTK_MAX_MODELS], *sysB[DARTK_MAX_MODELS], *sysC[DARTK_MAX_MODELS], *sysI[DARTK_MAX_MODELS][DARTK_MAX_MODELS];
+    dartk_da_point *ptsList[DARTK_MAX_MODELS];
     for (int m = 0; m < n; ++m) {
         const ModelView &v = mods[m]->v;
         MultiSolveModel &s = h.m[m];
-        const int redArt = s.redArt, S = sys_size(s.dims);
+        const int redArt = s.redArt;
         s.v = v;
-        s.A = mm[m].d_A; s.map = mm[m].d_map; s.redArtPtr = mm[m].d_redArt;
+        s.A = mm[m].d_A; s.map = mm[m].d_map;
+        s.redArtPtr = batch ? d_redArtBatch + redOff[m] : mm[m].d_redArt;
         s.b = fl + tables.size();
         for (int f = 0; f < v.nJoints; ++f) tables.push_back(mm[m].h_b ? mm[m].h_b[f] : 0.0f);
         s.redMin = fl + tables.size();
         for (int r = 0; r < redArt; ++r) tables.push_back(mm[m].h_redMin[r]);
         s.redMax = fl + tables.size();
         for (int r = 0; r < redArt; ++r) tables.push_back(mm[m].h_redMax[r]);
-        T_obs[m] = fl + tables.size(); tables.resize(tables.size() + 12, 0.0f);
-        T_pair[m] = fl + tables.size(); tables.resize(tables.size() + 24, 0.0f);
         s.reg = mm[m].regularization; s.regScaled = mm[m].regularizationScaled;
         s.countA = useA ? d_countA + m : nullptr;
         s.countB = useB ? d_countB + m : nullptr;
-        (void)S;
+        ptsList[m] = batch ? reinterpret_cast<dartk_da_point *>((char *)base + o_pts) + (size_t)m * nPix * nFrames : mm[m].d_pts;
     }
-    float *sysBase = fl + tables.size();
+    float *tabBase = fl + tableFloats;                       // frame 0's [T_obs | T_pair] table
+    for (int m = 0; m < n; ++m) { T_obs[m] = tabBase + 12 * m; T_pair[m] = tabBase + 12 * n + 24 * m; }
+    float *sysBase = tabBase + (size_t)nFrames * tabStride;  // frame 0's systems
     size_t so = 0;
     for (int m = 0; m < n; ++m) {
         MultiSolveModel &s = h.m[m];
@@ -278,21 +358,29 @@ int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *
     h.nModels = n; h.D = D; h.numIterations = o->numIterations;
     h.lambdaA = o->lambdaObsToMod; h.lambdaB = o->lambdaModToObs;
     h.iterInfo = d_iterInfo; h.firstSystem = d_firstSystem;
+    h.fb = fb; h.redStride = batch ? redTotal : 0; h.infoStride = batch ? (size_t)o->numIterations * n * 8 : 0; h.T_mcs = d_T_mcs;
     DARTK_HIP(hipMemcpyAsync(d_args, &h, sizeof(h), hipMemcpyHostToDevice, st));
     if (!tables.empty()) DARTK_HIP(hipMemcpyAsync(fl, tables.data(), sizeof(float) * tables.size(), hipMemcpyHostToDevice, st));
     DARTK_HIP(hipStreamSynchronize(st));        // h and tables are host temporaries
+
+    const int ldU = (D + 1) | 1;
+    const size_t ldsSolve = sizeof(float) * ((size_t)2 * D * ldU + 2 * D + 64 + 12 * (size_t)maxFrames + 8);
+    DARTK_REQUIRE(ldsSolve <= 160 * 1024, "LDS requirement exceeds 160 KiB");
+    if (ldsSolve > 64 * 1024)
+        DARTK_HIP(hipFuncSetAttribute((const void *)multi_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
+    BatchScope scope(fb);       // every launcher below covers all frames
+    if (batch)                  // import the caller's poses: T_mc, projection of the reduced articulation, forward kinematics
+        hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64), ldsSolve, st, d_args, -1);
 
     // association argument block (pose arrays are updated in place, so once per call)
     void *d_assocArgs = nullptr;
     if (useA) {
         float thr[DARTK_MAX_MODELS], po[DARTK_MAX_MODELS], pn[3 * DARTK_MAX_MODELS];
-        dartk_da_point *pts[DARTK_MAX_MODELS];
         for (int m = 0; m < n; ++m) {
             thr[m] = mm[m].distThreshold; po[m] = mm[m].planeOffset;
             for (int k = 0; k < 3; ++k) pn[3 * m + k] = mm[m].planeNormal[k];
-            pts[m] = mm[m].d_pts;
         }
-        rc = gn_assoc_multi_prepare(n, mods, thr, po, pn, pts, &d_assocArgs, st);
+        rc = gn_assoc_multi_prepare(n, mods, thr, po, pn, ptsList, &d_assocArgs, st);
         if (rc) return rc;
     }
     // generateObsSdf per model with its start pose (optimizer.cpp:574-580); the full-pose mod->obs wrapper works in that frame
@@ -301,29 +389,34 @@ int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *
             ProfScope ps(DARTK_PROF_OBS_SDF, st);
             rc = gn_obs_sdf_build(d_vert, width, height, mods[m], o->focalLength, st);
             if (rc) return rc;
-            DARTK_HIP(hipMemcpyAsync(T_obs[m], mods[m]->v.T_mc, 12 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            DARTK_HIP(hipMemcpy2DAsync(T_obs[m], sizeof(float) * (batch ? tabStride : 12), mods[m]->v.T_mc,
+                                       sizeof(float) * (batch ? mods[m]->v.poseStride : 12), 12 * sizeof(float), nFrames,
+                                       hipMemcpyDeviceToDevice, st));
         }
     }
-    const int ldU = (D + 1) | 1;
-    const size_t ldsSolve = sizeof(float) * ((size_t)2 * D * ldU + 2 * D + 64 + 12 * (size_t)maxFrames + 8);
-    DARTK_REQUIRE(ldsSolve <= 160 * 1024, "LDS requirement exceeds 160 KiB");
-    if (ldsSolve > 64 * 1024)
-        DARTK_HIP(hipFuncSetAttribute((const void *)multi_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
-    const int nPix = width * height;
     // Three chains per iteration meet only in the solve: ray-cast -> cull -> mod->obs (the longest, on the caller's stream),
     // association -> obs->mod, and the intersection terms; the two shorter ones run on the side streams, each term wrapper
     // writing its partial systems into its chain's lane of the slab buffer.
     struct LaneGuard { Workspace *w; ~LaneGuard() { w->partialLane = 0; } } laneGuard{ws};
-    size_t traceOff[DARTK_MAX_MODELS], traceFloats = 0;         // every model's slice of the ray-cast trace buffer
-    for (int m = 0; m < n; ++m) { traceOff[m] = traceFloats; traceFloats += 2 * (size_t)o->predWidth * o->predHeight * mods[m]->v.nSdfs; }
-    if (useB) { rc = gn_raycast_reserve(traceFloats); if (rc) return rc; }
+    if (useB) { rc = gn_raycast_reserve(traceFloats * nFrames); if (rc) return rc; }
     const bool par = o->numIterations > 0 && getenv("DARTK_MULTI_ONE_STREAM") == nullptr;
     hipStream_t stA = par ? ws->auxStream : st, stC = par ? ws->auxStream2 : st;
+    // on an error after the fork the caller's stream must still order after the side streams (they write the slab, trace and
+    // system buffers the next call reuses)
+    struct JoinGuard {
+        Workspace *w; hipStream_t st, a, c; bool on;
+        ~JoinGuard() {
+            if (!on) return;
+            (void)hipEventRecord(w->evJoin, a); (void)hipEventRecord(w->evJoin2, c);
+            (void)hipStreamWaitEvent(st, w->evJoin, 0); (void)hipStreamWaitEvent(st, w->evJoin2, 0);
+        }
+    } joinGuard{ws, st, stA, stC, false};
     for (int it = 0; it < o->numIterations; ++it) {
         if (par) {      // the poses of this iteration are final on `st`
             DARTK_HIP(hipEventRecord(ws->evFork, st));
             DARTK_HIP(hipStreamWaitEvent(stA, ws->evFork, 0));
             DARTK_HIP(hipStreamWaitEvent(stC, ws->evFork, 0));
+            joinGuard.on = true;
         }
         ws->partialLane = 0;
         if (useB) {     // raytracePrediction of every model into one map + cullUnobservable (:610-618)
@@ -342,7 +435,7 @@ int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *
             rc = gn_launch_raycast_replay_cull_multi(o->predFl[0], o->predFl[1], ppx, ppy, o->predWidth, o->predHeight, n, mods, traceOff,
                                                      d_prediction, d_vert, width, height, st);
             if (rc) return rc;
-            DARTK_HIP(hipMemsetAsync(d_countB, 0, n * sizeof(int), st));
+            DARTK_HIP(hipMemsetAsync(d_countB, 0, (batch ? (size_t)DARTK_MAX_MODELS * nFrames : (size_t)n) * sizeof(int), st));
             for (int m = 0; m < n; ++m) {   // reduced wrappers use the model's current T_mc, the full one T_obsSdf_c (modToObs.cu:851-988 vs :713-780)
                 const MultiSolveModel &s = h.m[m];
                 ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
@@ -361,7 +454,7 @@ int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *
             for (int m = 0; m < n; ++m) {
                 const MultiSolveModel &s = h.m[m];
                 ProfScope ps(DARTK_PROF_FUSED_OBS2MOD, stA);
-                rc = gn_launch_ne_obs2mod_dev(s.redType, 6 + mods[m]->v.nJoints, s.dims, d_vert, mods[m], o->huberDelta, mm[m].d_pts,
+                rc = gn_launch_ne_obs2mod_dev(s.redType, 6 + mods[m]->v.nJoints, s.dims, d_vert, mods[m], o->huberDelta, ptsList[m],
                                               d_countA + m, nPix, mm[m].d_A, mm[m].d_map, sysA[m], stA);
                 if (rc) return rc;
             }
@@ -390,12 +483,77 @@ int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *
             DARTK_HIP(hipEventRecord(ws->evJoin2, stC));
             DARTK_HIP(hipStreamWaitEvent(st, ws->evJoin, 0));
             DARTK_HIP(hipStreamWaitEvent(st, ws->evJoin2, 0));
+            joinGuard.on = false;
         }
         {
             ProfScope ps(DARTK_PROF_SOLVE, st);
-            hipLaunchKernelGGL(multi_solve_kernel, dim3(1), dim3(64), ldsSolve, st, d_args, it);
+            hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64), ldsSolve, st, d_args, it);
         }
         DARTK_HIP(hipGetLastError());
+    }
+    if (batch) {                // export the poses
+        hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64), ldsSolve, st, d_args, -2);
+        DARTK_HIP(hipGetLastError());
+    }
+    return DARTK_OK;
+}
+
+}  // namespace dartk
+
+using namespace dartk;
+
+extern "C" {
+
+int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *mm, const float *d_vert, const float *d_norm,
+                         int width, int height, float *d_prediction, float *d_iterInfo, float *d_firstSystem, void *stream) {
+    DARTK_REQUIRE(o && mm && d_vert && d_norm, "dartk_optimize_poses: null argument");
+    const int n = o->nModels;
+    DARTK_REQUIRE(n >= 1 && n <= DARTK_MAX_MODELS, "nModels %d out of range [1,%d]", n, DARTK_MAX_MODELS);
+    DARTK_REQUIRE(width > 0 && height > 0 && (long long)width * height < (1ll << 31), "bad map size %dx%d", width, height);
+    DARTK_REQUIRE(o->numIterations >= 0, "negative iteration count");
+    if (o->lambdaModToObs > 0) {
+        DARTK_REQUIRE(d_prediction && o->predWidth > 0 && o->predHeight > 0, "mod->obs term needs a prediction buffer");
+        // cullUnobservable reads the 2x2 observation pixels at (px*ow/pw, py*oh/ph): the prediction must be coarser than the
+        // observation map (the same requirement as dartk_cull_unobservable)
+        DARTK_REQUIRE((o->predWidth - 1) * width / o->predWidth + 1 < width && (o->predHeight - 1) * height / o->predHeight + 1 < height,
+                      "cullUnobservable reads a 2x2 observation neighbourhood: the prediction (%dx%d) must be smaller than the observation map (%dx%d)",
+                      o->predWidth, o->predHeight, width, height);
+    }
+    return optimize_poses_impl(o, mm, 1, d_vert, d_norm, width, height, d_prediction, nullptr, nullptr, d_iterInfo, d_firstSystem, as_stream(stream));
+}
+
+int dartk_optimize_poses_batch(const dartk_multi_options *o, const dartk_multi_model *mm, int nFrames, const float *d_vert,
+                               const float *d_norm, int width, int height, float *d_T_mcs, float *d_redArt, float *d_iterInfo,
+                               void *stream) {
+    DARTK_REQUIRE(o && mm && d_vert && d_norm && d_T_mcs, "dartk_optimize_poses_batch: null argument");
+    const int n = o->nModels;
+    DARTK_REQUIRE(n >= 1 && n <= DARTK_MAX_MODELS, "nModels %d out of range [1,%d]", n, DARTK_MAX_MODELS);
+    DARTK_REQUIRE(nFrames >= 1 && nFrames <= 65535, "nFrames %d out of range [1,65535]", nFrames);
+    DARTK_REQUIRE(width > 0 && height > 0 && (long long)width * height < (1ll << 31), "bad map size %dx%d", width, height);
+    DARTK_REQUIRE(o->numIterations >= 0, "negative iteration count");
+    int redTotal = 0;
+    for (int m = 0; m < n; ++m) {
+        DARTK_REQUIRE(mm[m].model, "dartk_optimize_poses_batch: null model %d", m);
+        redTotal += mm[m].redType == 0 ? reinterpret_cast<Model *>(mm[m].model)->v.nJoints : mm[m].redArtDims;
+    }
+    DARTK_REQUIRE(redTotal == 0 || d_redArt, "dartk_optimize_poses_batch: reduced articulations missing");
+    if (o->lambdaModToObs > 0) {
+        DARTK_REQUIRE(o->predWidth > 0 && o->predHeight > 0, "mod->obs term needs a prediction size");
+        DARTK_REQUIRE((o->predWidth - 1) * width / o->predWidth + 1 < width && (o->predHeight - 1) * height / o->predHeight + 1 < height,
+                      "cullUnobservable reads a 2x2 observation neighbourhood: the prediction (%dx%d) must be smaller than the observation map (%dx%d)",
+                      o->predWidth, o->predHeight, width, height);
+    }
+    // frames in chunks that bound the per-call device memory (association lists, traces, prediction maps: ~50 MB per 1280x720 frame)
+    static const char *env = getenv("DARTK_BATCH_CHUNK");
+    const int chunk = env ? atoi(env) : 64;
+    hipStream_t st = as_stream(stream);
+    const size_t mapFloats = 4 * (size_t)width * height;
+    for (int f0 = 0; f0 < nFrames; f0 += chunk) {
+        const int nf = nFrames - f0 < chunk ? nFrames - f0 : chunk;
+        int rc = optimize_poses_impl(o, mm, nf, d_vert + f0 * mapFloats, d_norm + f0 * mapFloats, width, height, nullptr,
+                                     d_T_mcs + (size_t)f0 * n * 12, d_redArt ? d_redArt + (size_t)f0 * redTotal : nullptr,
+                                     d_iterInfo ? d_iterInfo + (size_t)f0 * o->numIterations * n * 8 : nullptr, nullptr, st);
+        if (rc) return rc;
     }
     return DARTK_OK;
 }

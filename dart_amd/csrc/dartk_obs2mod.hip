@@ -74,8 +74,11 @@ struct MultiArgs {
 template <bool DBG>
 __global__ void __launch_bounds__(256)
 assoc_multi_kernel(const float4 *__restrict__ vert, int nPix, const MultiArgs *__restrict__ args,
-                   int *__restrict__ lastElement, int *__restrict__ dbgDA, float *__restrict__ dbgErr) {
+                   int *__restrict__ lastElement, int *__restrict__ dbgDA, float *__restrict__ dbgErr, FrameBatch fb) {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    const int frame = blockIdx.y;                    // frame of a batch (0 otherwise)
+    vert += (size_t)frame * fb.vert;
+    lastElement += (size_t)frame * fb.counts;
     int aModel = -1, aGrid = -1;
     float sdfError = 1e20f;
     if (index < nPix) {
@@ -88,13 +91,14 @@ assoc_multi_kernel(const float4 *__restrict__ vert, int nPix, const MultiArgs *_
             const int nModels = args->nModels;
             for (int mi = 0; mi < nModels; ++mi) {
                 const ModelView &m = args->m[mi];
-                const float *__restrict__ T_mc = m.T_mc;
+                const size_t po = (size_t)frame * (size_t)m.poseStride;
+                const float *__restrict__ T_mc = m.T_mc + po;
                 const f3 xm = se3_apply_w(T_mc, xc.x, xc.y, xc.z, xc.w);
                 f3 pn; pn.x = args->pn[mi][0]; pn.y = args->pn[mi][1]; pn.z = args->pn[mi][2];
                 if (!(dot(xm, pn) >= args->planeOffset[mi])) continue;
                 const float thr = args->distThr[mi];
                 const int slot = keep_slot(thr);
-                const float *__restrict__ T_fm = m.T_fm;
+                const float *__restrict__ T_fm = m.T_fm + po;
                 for (int g = 0; g < m.nSdfs; ++g) {
                     const int f = m.sdfFrame[g];
                     const f3 xf = se3_apply_w(T_fm + 12 * f, xm.x, xm.y, xm.z, xc.w);
@@ -126,7 +130,7 @@ assoc_multi_kernel(const float4 *__restrict__ vert, int nPix, const MultiArgs *_
             const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             dartk_da_point p;
             p.index = index; p.dataAssociation = aGrid; p.error = sdfError;
-            args->pts[mi][base + __popcll(mask & lt)] = p;
+            args->pts[mi][(size_t)frame * fb.pts + base + __popcll(mask & lt)] = p;
         }
     }
 }
@@ -139,11 +143,15 @@ assoc_multi_kernel(const float4 *__restrict__ vert, int nPix, const MultiArgs *_
 // -----------------------------------------------------------------------------------------------------
 template <int PPT, int RED>
 __global__ void __launch_bounds__(NE_BLOCK)
-ne_obs2mod_kernel(const dartk_da_point *__restrict__ pts, const float4 *__restrict__ vert, int nPoints, ModelView m,
+ne_obs2mod_kernel(const dartk_da_point *__restrict__ pts, const float4 *__restrict__ vert, int nPoints, ModelView m_in,
                   float huberDelta, int redDims, const float *__restrict__ dtheta_dalpha,
-                  const int *__restrict__ mapping, float *__restrict__ slabs, const int *__restrict__ d_count) {
+                  const int *__restrict__ mapping, float *__restrict__ slabs, const int *__restrict__ d_count, FrameBatch fb) {
     extern __shared__ float lds[];
-    if (d_count) nPoints = min(nPoints, *d_count);      // device-resident loops: the list length stays on the device
+    ModelView m = m_in;
+    select_frame(m, blockIdx.y);                        // frame of a batch (0 otherwise)
+    pts += (size_t)blockIdx.y * fb.pts;
+    vert += (size_t)blockIdx.y * fb.vert;
+    if (d_count) nPoints = min(nPoints, d_count[(size_t)blockIdx.y * fb.counts]);      // device-resident loops: the list length stays on the device
     const int fullDims = 6 + m.nJoints;
     const int d = RED ? redDims : fullDims;
     const bool drop = (RED != 0);
@@ -200,7 +208,7 @@ ne_obs2mod_kernel(const dartk_da_point *__restrict__ pts, const float4 *__restri
         acc.accumulate(rows, ld, n);
         __syncthreads();
     }
-    acc.store(slabs + (size_t)blockIdx.x * sys_size(d), sys_size(d));
+    acc.store(slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * sys_size(d), sys_size(d));
 }
 
 size_t ne_obs2mod_lds_bytes(const ModelView &m, int d, int red) {
@@ -240,7 +248,7 @@ static int launch_ne_obs2mod(int fullDims, int redDims, const float *d_vert, Mod
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
         hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, nElements, m,         \
-                           huberDelta, redDims, d_A, d_map, lane_partials(ws), (const int *)nullptr);                \
+                           huberDelta, redDims, d_A, d_map, lane_partials(ws), (const int *)nullptr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0}); \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_NE(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_NE(6);
@@ -263,9 +271,11 @@ static int launch_ne_obs2mod_dev(int fullDims, int redDims, const float *d_vert,
     Workspace *ws;
     int rc = get_workspace(&ws);
     if (rc) return rc;
+    const FrameBatch fb = cur_batch();
     const int nTiles = (maxElements + NE_BLOCK - 1) / NE_BLOCK;
-    const int nBlocks = nTiles < 512 ? (nTiles > 0 ? nTiles : 1) : 512;
-    rc = ensure_partials(ws, (size_t)nBlocks * S);
+    const int cap = fb.n > 1 ? 128 : 512;           // a batch fills the chip with its frames: fewer, longer workgroups per frame
+    const int nBlocks = nTiles < cap ? (nTiles > 0 ? nTiles : 1) : cap;
+    rc = ensure_partials(ws, (size_t)fb.n * nBlocks * S);
     if (rc) return rc;
     const size_t ldsBytes = ne_obs2mod_lds_bytes(m, d, RED);
     DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
@@ -275,8 +285,8 @@ static int launch_ne_obs2mod_dev(int fullDims, int redDims, const float *d_vert,
         auto kfn = ne_obs2mod_kernel<PPT_, RED>;                                                                \
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
-        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, maxElements, m,       \
-                           huberDelta, redDims, d_A, d_map, lane_partials(ws), d_count);                             \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks, fb.n), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, maxElements, m, \
+                           huberDelta, redDims, d_A, d_map, lane_partials(ws), d_count, fb);                         \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_NE(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_NE(6);
@@ -347,10 +357,10 @@ static int launch_ne_obs2mod_noalloc(int dims, const float *d_vert, Model *mod, 
     const float4 *vert = reinterpret_cast<const float4 *>(d_vert);
     if (S <= 3 * NE_BLOCK)
         hipLaunchKernelGGL((ne_obs2mod_kernel<3, 0>), dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, nElements, m, huberDelta,
-                           dims, (const float *)nullptr, (const int *)nullptr, slabs, (const int *)nullptr);
+                           dims, (const float *)nullptr, (const int *)nullptr, slabs, (const int *)nullptr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0});
     else
         hipLaunchKernelGGL((ne_obs2mod_kernel<6, 0>), dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, nElements, m, huberDelta,
-                           dims, (const float *)nullptr, (const int *)nullptr, slabs, (const int *)nullptr);
+                           dims, (const float *)nullptr, (const int *)nullptr, slabs, (const int *)nullptr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0});
     DARTK_HIP(hipGetLastError());
     return launch_reduce_slabs(slabs, nBlocks, S, d_result, 1, st);
 }
@@ -377,9 +387,10 @@ int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr
     return DARTK_OK;
 }
 int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void *d_args, int *d_last, hipStream_t st) {
-    DARTK_HIP(hipMemsetAsync(d_last, 0, nModels * sizeof(int), st));
-    hipLaunchKernelGGL(assoc_multi_kernel<false>, dim3((nPix + 255) / 256), dim3(256), 0, st, (const float4 *)d_vert, nPix,
-                       (const MultiArgs *)d_args, d_last, nullptr, nullptr);
+    const FrameBatch fb = cur_batch();
+    DARTK_HIP(hipMemsetAsync(d_last, 0, (fb.n > 1 ? (size_t)fb.n * fb.counts : (size_t)nModels) * sizeof(int), st));
+    hipLaunchKernelGGL(assoc_multi_kernel<false>, dim3((nPix + 255) / 256, fb.n), dim3(256), 0, st, (const float4 *)d_vert, nPix,
+                       (const MultiArgs *)d_args, d_last, nullptr, nullptr, fb);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
@@ -453,9 +464,9 @@ int dartk_assoc_multi(const float *d_vert, const float *d_norm, int width, int h
     const int nPix = width * height;
     const dim3 grid((nPix + 255) / 256), block(256);
     if (d_dbgDA || d_dbgErr)
-        hipLaunchKernelGGL(assoc_multi_kernel<true>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, d_dbgDA, d_dbgErr);
+        hipLaunchKernelGGL(assoc_multi_kernel<true>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, d_dbgDA, d_dbgErr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0});
     else
-        hipLaunchKernelGGL(assoc_multi_kernel<false>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, nullptr, nullptr);
+        hipLaunchKernelGGL(assoc_multi_kernel<false>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, nullptr, nullptr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0});
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }

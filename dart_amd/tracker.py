@@ -186,6 +186,66 @@ class Tracker:
             self.first_system = first.cpu().numpy()
         return -1.0
 
+    # ---- a batch of independent frames (BASELINE configs[4]), dartk_optimize_poses_batch
+    def optimizePosesBatch(self, vert, norm, T_mcs, red_arts, debug=False):
+        """Optimizer::optimizePoses for F independent frames in one library call. vert / norm: CUDA tensors [F,H,W,4];
+        T_mcs: [F, nModels, 12] start transforms (numpy or CUDA tensor); red_arts: [F, sum of reduced articulation dims]
+        (model order). Returns (T_mcs, red_arts) as numpy arrays (or tensors when tensors were passed); the tracker's own
+        poses are not touched. Models, reductions, clouds and options are the tracker's."""
+        import ctypes as C
+        from . import _abi
+        from ._abi import check, lib
+        if self.priors:
+            raise NotImplementedError("priors in the observation loop are not wired up yet (device priors live in TrackerNoObs)")
+        o, n = self.opts, len(self.models)
+        dev = self.prediction.device
+        F_, h, w = vert.shape[0], vert.shape[1], vert.shape[2]
+        as_tensor = torch.is_tensor(T_mcs)
+        T_d = (T_mcs if as_tensor else torch.from_numpy(np.ascontiguousarray(T_mcs, dtype=F))).to(dev).reshape(F_, n, 12).contiguous().clone()
+        ra_total = int(sum(p.getReducedArticulatedDimensions() for p in self.poses))
+        ra_d = (red_arts if torch.is_tensor(red_arts) else torch.from_numpy(np.ascontiguousarray(red_arts, dtype=F))).to(dev).reshape(F_, max(ra_total, 1))[:, :max(ra_total, 1)].contiguous().clone() \
+            if ra_total else torch.zeros((F_, 1), dtype=torch.float32, device=dev)
+        mm = (_abi.MultiModelC * n)()
+        keep = []
+        for m in range(n):
+            p, red = self.poses[m], self.red_dev[m]
+            ra_n = p.getReducedArticulatedDimensions()
+            mins = np.asarray([p.getReducedMin(i) for i in range(ra_n)] or [0.0], dtype=F)
+            maxs = np.asarray([p.getReducedMax(i) for i in range(ra_n)] or [0.0], dtype=F)
+            b = np.ascontiguousarray(getattr(p._reduction, "_b", np.zeros(self.host_models[m].n_joints, dtype=F)), dtype=F)
+            keep += [mins, maxs, b]
+            c = mm[m]
+            c.model = self.models[m].handle
+            c.redType = 0 if red is None else (2 if red[0] == "map" else 1)
+            c.redArtDims = ra_n
+            c.d_A = device._ptr(red[1]) if red is not None and red[0] == "linear" else None
+            c.d_map = device._ptr(red[1]) if red is not None and red[0] == "map" else None
+            c.h_b, c.h_redMin, c.h_redMax = _abi.fptr(b), _abi.fptr(mins), _abi.fptr(maxs)
+            c.d_redArt = None
+            c.d_cloud, c.nCloud = device._ptr(self.clouds[m]), int(self.clouds[m].shape[0])
+            c.d_potential = device._ptr(self.potentials[m])
+            c.d_pts = None
+            c.distThreshold, c.planeOffset = float(o.distThreshold[m]), float(o.planeOffset[m])
+            for k in range(3):
+                c.planeNormal[k] = float(o.planeNormal[m][k])
+            c.regularization, c.regularizationScaled = float(o.regularization[m]), float(o.regularizationScaled[m])
+        mo = _abi.MultiOptionsC()
+        mo.numIterations, mo.nModels = int(o.numIterations), n
+        mo.lambdaObsToMod, mo.lambdaModToObs = float(o.lambdaObsToMod), float(o.lambdaModToObs)
+        mo.huberDelta, mo.focalLength = float(o.huberDelta), float(o.focalLength)
+        mo.predWidth, mo.predHeight = self.pred_width, self.pred_height
+        mo.predFl[0], mo.predFl[1] = float(self.pred_fl[0]), float(self.pred_fl[1])
+        for i in range(n * n):
+            mo.lambdaIntersection[i] = float(o.lambdaIntersection[i])
+        info = torch.zeros((F_, max(o.numIterations, 1), n, 8), dtype=torch.float32, device=dev) if debug else None
+        check(lib().dartk_optimize_poses_batch(C.byref(mo), mm, F_, device._ptr(vert), device._ptr(norm), w, h, device._ptr(T_d),
+                                               device._ptr(ra_d) if ra_total else None, device._ptr(info), device._stream()))
+        if debug:
+            self.iteration_summaries = info.cpu().numpy()
+        if as_tensor:
+            return T_d, ra_d[:, :ra_total]
+        return T_d.cpu().numpy(), ra_d[:, :ra_total].cpu().numpy()
+
     # ---- Optimizer::optimizePoses (optimizer.cpp:524-781), host-driven: one C-ABI call per term as the reference drives it
     def optimizePoses(self, vert, norm, debug=False):
         if self.priors:

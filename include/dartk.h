@@ -337,6 +337,21 @@ int dartk_optimize_poses(const dartk_multi_options *opts, const dartk_multi_mode
                          const float *d_norm, int width, int height, float *d_prediction, float *d_iterInfo,
                          float *d_firstSystem, void *stream);
 
+/* Optimizer::optimizePoses (optimizer.cpp:524-781) for nFrames INDEPENDENT frames in one call (BASELINE configs[4]: a batch of
+ * recorded frames tracked from their own start poses; the reference would loop over the frames on the host). Every kernel launch
+ * covers all frames (grid.y = frame, the solve one wave per frame): the frames share the models' SDFs, tables, reductions,
+ * clouds and options (`models`, as for dartk_optimize_poses; its d_redArt / d_pts fields are not used here) and differ in
+ *   d_vert / d_norm   [nFrames][height*width*4]  observation maps, frame-major
+ *   d_T_mcs           [nFrames][nModels][12]     camera->model transforms, in/out
+ *   d_redArt          [nFrames][sum of reduced articulation dims, model order]  in/out (NULL when no model is articulated)
+ * Optional d_iterInfo [nFrames][numIterations][nModels][8] as for dartk_optimize_poses. The model handles' own poses are not
+ * touched. Frames are processed in chunks of 64 (DARTK_BATCH_CHUNK) to bound the device memory held for association lists,
+ * ray-cast traces and prediction maps. Per frame the result equals a dartk_optimize_poses call on that frame (same kernels;
+ * sums of the atomically appended association lists differ in order, as between two single calls). */
+int dartk_optimize_poses_batch(const dartk_multi_options *opts, const dartk_multi_model *models, int nFrames, const float *d_vert,
+                               const float *d_norm, int width, int height, float *d_T_mcs, float *d_redArt, float *d_iterInfo,
+                               void *stream);
+
 /* ------------------------------------------------------------------ measurement (no reference counterpart) */
 /* Per-kernel-class device time of the Gauss-Newton loops, measured with HIP events recorded on the launch stream
  * around every launch between dartk_profile_begin() and dartk_profile_end(). Used by bench.py's roofline leg;
