@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0
-TRACE_BYTES_PER_PAIR = 8        # ray-cast trace record per (prediction pixel, SDF): {detection t, hit t}
+TRACE_BYTES_PER_PAIR = 8        # ray-cast trace record per traced (prediction pixel, SDF) pair: {detection t, hit t}
 PROF_NAMES = ["obs_sdf_build", "raycast_trace_kernel", "fused_obs2mod_kernel", "ne_mod2obs_kernel", "ne_self_intersection_kernel",
               "gn_solve_single_kernel", "raycast_replay_kernel", "valid_pixel_compaction", "gn_reduce_kernel",
               "noobs_terms_kernel<intersection>", "noobs_solve_kernel", "noobs_terms_kernel<priors>"]
@@ -264,7 +264,7 @@ def main():
         n_pred = float(info_np[:, 4].mean())
         n_sdfs = len(sc.host_model.sdfs)
         lk = {"fused_obs2mod_kernel": (cnt[1] + cnt[2]) / iters, "raycast_trace_kernel": cnt[4] / iters, "ne_mod2obs_kernel": cnt[5] / iters}
-        trace_bytes = float(TRACE_BYTES_PER_PAIR) * P * n_sdfs
+        trace_bytes = float(TRACE_BYTES_PER_PAIR) * cnt[0] / iters      # records written: the (pixel, SDF) pairs inside the SDFs' screen rectangles
         bytes_per_launch = {
             # 4 B index + 16 B vertex per valid pixel + 32 B per trilinear lookup performed (association scan of the SDFs
             # whose keep box holds the point + the 6-lookup gradient of the associated ones) + 16 B normal per candidate
@@ -291,6 +291,7 @@ def main():
             "whole_iteration": {"algorithmic_bytes": round(it_bytes), "achieved_GBs": round(it_bytes / (elapsed / max(n_steps * iters, 1)) / 1e9, 2),
                                 "frac": round(it_bytes / (elapsed / max(n_steps * iters, 1)) / 1e9 / HBM_PEAK_GBS, 5)},
             "counts": {"valid_pixels": n_valid, "associated_per_iter": n_assoc, "predicted_per_iter": n_pred,
+                       "trace_records_per_iter": cnt[0] / iters, "dense_pairs_per_iter": P * n_sdfs,
                        "lookups_performed_per_iter": {"association_scan": cnt[1] / iters, "association_gradient": cnt[2] / iters,
                                                       "raycast_march": cnt[4] / iters, "mod2obs": cnt[5] / iters}},
             "note": "latency-bound at batch 1: one frame's working set (SDFs L2/MALL-resident) cannot approach the HBM roof; the "

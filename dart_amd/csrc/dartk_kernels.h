@@ -34,6 +34,10 @@ int ensure_partials(Workspace *w, size_t floats);
 int noalloc_scratch(float **out);      // dartk_obs2mod.hip: device address of the no-allocation entry point's scratch array
 int get_multi_args_buffer(void **d_ptr, size_t bytes);
 int ensure_ray_buf(Workspace *w, size_t floats);
+// floats of ray-cast trace records one model can need: {detection t, hit t} per pixel of every 8x8 tile, per SDF
+inline size_t ray_trace_floats(int width, int height, int nSdfs) {
+    return (size_t)2 * 64 * ((width + 7) / 8) * ((height + 7) / 8) * (size_t)nSdfs;
+}
 int ensure_valid_idx(Workspace *w, size_t ints);
 
 // kernel-only launchers used by the device-resident Gauss-Newton loops (dartk_gn.hip)

@@ -42,171 +42,204 @@ __device__ __forceinline__ RayGeom ray_in_frame(const float *T_fc, int x, int y,
     return g;
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Sparse traces. A ray can only find a crossing in an SDF if it passes the SDF's keep box for the level (see below), so per SDF
+// only the 8x8 pixel tiles inside the screen rectangle of that box are traced at all; everything outside is "no crossing"
+// without a record. Task t of a model = (SDF s, tile k of s's rectangle), numbered SDF by SDF (off[] = exclusive prefix sum of
+// the rectangles' tile counts); its 64 records live at trace[t*64 + (y&7)*8 + (x&7)]. The table is recomputed from the pose
+// in the prologue of every kernel that needs it (same function, same arithmetic: trace and replay agree by construction):
+// no extra launch on the iteration's critical chain, and the reference's dense [nSdfs][pixels] traffic (8 B per pair, written
+// and read every iteration, 99 % of it "no crossing") shrinks to the pairs that can matter.
+// Layout of the table sR: x0[n] | y0[n] | w[n] | off[n+1]   (tiles).
+// -----------------------------------------------------------------------------------------------------
+static constexpr int kMaxRaySdfs = 256;
+static constexpr int kRectInts = 4 * kMaxRaySdfs + 1;
+
+__device__ __forceinline__ void stage_ray_rects(const ModelView &m, float levelSet, float flx, float fly, float ppx, float ppy,
+                                                int width, int height, int *sR) {
+    const int n = m.nSdfs;
+    const int tilesX = (width + 7) >> 3, tilesY = (height + 7) >> 3;
+    const int slot = (levelSet <= 0.0f) ? 0 : keep_slot(levelSet);
+    int *sH = sR + 3 * n + 1;        // heights, in the slots the prefix sum overwrites last to first
+    for (int s = threadIdx.x; s < n; s += blockDim.x) {
+        const SdfDev &sdf = m.sdfs[s];
+        const int f = m.sdfFrame[s];
+        float T_cm[12], T_mf[12], T_cf[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { T_cm[i] = m.T_cm[i]; T_mf[i] = m.T_mf[12 * f + i]; }
+        se3_mul(T_cm, T_mf, T_cf);
+        const float dim[3] = {(float)sdf.dimx, (float)sdf.dimy, (float)sdf.dimz};
+        float lo[3], hi[3];
+        bool empty = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            // the box a marching sample must enter: the keep box where it is interior; where it reaches the planes the samples
+            // are clamped to (1 / dim-2) it extends to the face of the grid, beyond which no ray is marched (intersectBox)
+            float l = 0.0f, h = dim[a];
+            if (slot >= 0) {
+                const float kl = sdf.keepLo[slot][a], kh = sdf.keepHi[slot][a];
+                if (!(kl <= kh)) empty = true;
+                if (kl > 1.0f) l = kl - 0.05f;
+                if (kh < dim[a] - 2.0f) h = kh + 0.05f;
+            }
+            lo[a] = l; hi[a] = h;
+        }
+        int x0 = 0, y0 = 0, x1 = tilesX - 1, y1 = tilesY - 1;      // tiles, inclusive
+        if (empty) { x1 = -1; y1 = -1; }
+        else {
+            float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
+            bool behind = false;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float gx = (c & 1) ? hi[0] : lo[0], gy = (c & 2) ? hi[1] : lo[1], gz = (c & 4) ? hi[2] : lo[2];
+                const f3 pc = se3_apply_w(T_cf, sdf.ox + sdf.res * gx, sdf.oy + sdf.res * gy, sdf.oz + sdf.res * gz, 1.0f);
+                if (!(pc.z > 1e-3f)) behind = true;
+                const float u = pc.x / pc.z * flx + ppx, v = pc.y / pc.z * fly + ppy;
+                umin = fminf(umin, u); umax = fmaxf(umax, u); vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+            }
+            if (!behind) {
+                // pixel x looks along u = x + 0.5; two pixels of margin cover the rounding of this projection and of the rays
+                const float fx0 = floorf(umin - 0.5f) - 2.0f, fx1 = ceilf(umax - 0.5f) + 2.0f;
+                const float fy0 = floorf(vmin - 0.5f) - 2.0f, fy1 = ceilf(vmax - 0.5f) + 2.0f;
+                const int px0 = (int)fmaxf(fx0, 0.0f), px1 = (int)fminf(fx1, (float)(width - 1));
+                const int py0 = (int)fmaxf(fy0, 0.0f), py1 = (int)fminf(fy1, (float)(height - 1));
+                if (fx1 < 0.0f || fy1 < 0.0f || fx0 > (float)(width - 1) || fy0 > (float)(height - 1)) { x1 = -1; y1 = -1; }
+                else { x0 = px0 >> 3; x1 = px1 >> 3; y0 = py0 >> 3; y1 = py1 >> 3; }
+            }
+        }
+        const int w = x1 >= x0 ? x1 - x0 + 1 : 0, h = y1 >= y0 ? y1 - y0 + 1 : 0;
+        sR[s] = x0; sR[n + s] = y0; sR[2 * n + s] = w; sH[s] = h;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {         // exclusive prefix sum of the tile counts (a few dozen SDFs)
+        int run = 0;
+        for (int s = 0; s < n; ++s) {
+            const int cnt = sR[2 * n + s] * sH[s];
+            sR[3 * n + s] = run;     // overwrites sH[s-1] at most (already consumed)
+            run += cnt;
+        }
+        sR[4 * n] = run;
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(256)
 raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int height, ModelView m_in,
-                     float2 *__restrict__ trace /*[nSdfs][width*height]*/, float levelSet, FrameBatch fb) {
+                     float2 *__restrict__ trace /* [tasks][64], see stage_ray_rects */, float levelSet, FrameBatch fb) {
+    __shared__ int sR[kRectInts];
     ModelView m = m_in;
     select_frame(m, blockIdx.y);                    // frame of a batch (0 otherwise)
     trace += (size_t)blockIdx.y * (fb.trace >> 1);
-    const int tilesX = (width + 7) >> 3, tilesY = (height + 7) >> 3;
-    const int nTiles = tilesX * tilesY;
+    stage_ray_rects(m, levelSet, flx, fly, ppx, ppy, width, height, sR);
+    const int n = m.nSdfs;
+    const int nTasks = sR[4 * n];
     const int lane = threadIdx.x & 63;
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // tile fastest, SDF slowest
-    if (task >= nTiles * m.nSdfs) return;
-    const int s = task / nTiles, tile = task - s * nTiles;
-    const int x = (tile % tilesX) * 8 + (lane & 7);
-    const int y = (tile / tilesX) * 8 + (lane >> 3);
-    if (x >= width || y >= height) return;
-    float T_fc[12];
-    {
-        const int f = m.sdfFrame[s];
-        float T_fm[12], T_mc[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) { T_fm[i] = m.T_fm[12 * f + i]; T_mc[i] = m.T_mc[i]; }
-        se3_mul(T_fm, T_mc, T_fc);              // T_fms[f]*T_mc
-    }
-    const RayGeom g = ray_in_frame(T_fc, x, y, flx, fly, ppx, ppy);
-    const f3 of = g.of, dn = g.dn;
-    const SdfDev &sdf = m.sdfs[s];
-    const float smaxx = sdf.ox + sdf.res * (float)(unsigned)sdf.dimx;
-    const float smaxy = sdf.oy + sdf.res * (float)(unsigned)sdf.dimy;
-    const float smaxz = sdf.oz + sdf.res * (float)(unsigned)sdf.dimz;
-    const float hix = (float)((unsigned)sdf.dimx - 2u), hiy = (float)((unsigned)sdf.dimy - 2u), hiz = (float)((unsigned)sdf.dimz - 2u);
-    float t0, t1;   // intersectBox, raycast.cu:11-35
-    {
-        const float ix = 1.0f / dn.x, iy = 1.0f / dn.y, iz = 1.0f / dn.z;
-        const float bx = ix * (sdf.ox - of.x), by = iy * (sdf.oy - of.y), bz = iz * (sdf.oz - of.z);
-        const float tx = ix * (smaxx - of.x), ty = iy * (smaxy - of.y), tz = iz * (smaxz - of.z);
-        t0 = fmaxf(fmaxf(fminf(tx, bx), fminf(ty, by)), fminf(tz, bz));
-        t1 = fminf(fminf(fmaxf(tx, bx), fmaxf(ty, by)), fmaxf(tz, bz));
-    }
-    float det = 3.0e38f, hit = 0.0f;
-    bool march = t1 > t0;
-    // A crossing needs a sample with value <= levelSet, i.e. a sample inside the SDF's keep box for that level (SdfDev;
-    // samples are clamped to [1, dim-2], so a box side that reaches the clamp planes extends to infinity): a ray that
-    // misses the box is not marched at all -- it could only have ended with "no crossing". Most rays of a tile miss the
-    // few-centimetre link inside its 10 cm padding.
     const int slot = (levelSet <= 0.0f) ? 0 : keep_slot(levelSet);
-    if (march && slot >= 0) {
-        const float g0[3] = {(of.x - sdf.ox) / sdf.res, (of.y - sdf.oy) / sdf.res, (of.z - sdf.oz) / sdf.res};
-        const float gd[3] = {dn.x / sdf.res, dn.y / sdf.res, dn.z / sdf.res};
-        const float top[3] = {hix, hiy, hiz};
-        float tin = -3.0e38f, tout = 3.0e38f;
+    int s = 0;                                       // SDF of the current task: tasks are visited in increasing order
+    for (int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); task < nTasks; task += gridDim.x * 4) {
+        while (task >= sR[3 * n + s + 1]) ++s;       // wave-uniform
+        const int local = task - sR[3 * n + s], rw = sR[2 * n + s];
+        const int x = (sR[s] + local % rw) * 8 + (lane & 7);
+        const int y = (sR[n + s] + local / rw) * 8 + (lane >> 3);
+        if (x >= width || y >= height) continue;
+        float T_fc[12];
+        {
+            const int f = m.sdfFrame[s];
+            float T_fm[12], T_mc[12];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float lo = sdf.keepLo[slot][a], hi = sdf.keepHi[slot][a];
-            if (!(lo <= hi)) { tin = 1.0f; tout = 0.0f; break; }        // nothing at or below the level in this SDF
-            const bool openLo = lo <= 1.0f, openHi = hi >= top[a];
-            const float inv = 1.0f / gd[a];
-            float ta = ((lo - 0.05f) - g0[a]) * inv, tb = ((hi + 0.05f) - g0[a]) * inv;
-            if (openLo) ta = (gd[a] > 0) ? -3.0e38f : 3.0e38f;
-            if (openHi) tb = (gd[a] > 0) ? 3.0e38f : -3.0e38f;
-            if (gd[a] == 0.0f) {                                            // parallel to the slab: inside or never
-                const bool inside = (openLo || g0[a] >= lo - 0.05f) && (openHi || g0[a] <= hi + 0.05f);
-                ta = inside ? -3.0e38f : 3.0e38f; tb = inside ? 3.0e38f : -3.0e38f;
-            }
-            tin = fmaxf(tin, fminf(ta, tb));
-            tout = fminf(tout, fmaxf(ta, tb));
+            for (int i = 0; i < 12; ++i) { T_fm[i] = m.T_fm[12 * f + i]; T_mc[i] = m.T_mc[i]; }
+            se3_mul(T_fm, T_mc, T_fc);              // T_fms[f]*T_mc
         }
-        march = tin <= tout;
-    }
-    if (march) {
-        const float *data = m.grids + sdf.dataOff;
-        // header fields in registers for the march (the compiler does not hoist loads through the SdfDev reference)
-        const float res = sdf.res, rcp = sdf.rcpRes, ox = sdf.ox, oy = sdf.oy, oz = sdf.oz;
-        const bool exactDiv = sdf.divExact != 0;
-        const int dimx = sdf.dimx, dimy = sdf.dimy;
-        auto eval = [&](float tt) -> float {
-            f3 xf, xg;
-            xf.x = dn.x * tt + of.x; xf.y = dn.y * tt + of.y; xf.z = dn.z * tt + of.z;
-            const float dx = xf.x - ox, dy = xf.y - oy, dz = xf.z - oz;
-            if (exactDiv) { xg.x = div_exact(dx, res, rcp); xg.y = div_exact(dy, res, rcp); xg.z = div_exact(dz, res, rcp); }
-            else { xg.x = dx / res; xg.y = dy / res; xg.z = dz / res; }
-            xg.x = fmaxf(1.0f, fminf(xg.x, hix));
-            xg.y = fmaxf(1.0f, fminf(xg.y, hiy));
-            xg.z = fmaxf(1.0f, fminf(xg.z, hiz));
-            return grid_value<CNT_RAYCAST>(data, dimx, dimy, xg) * res;
-        };
-        float sdfValPrev = eval(t0);
-        float tPrev = t0;
+        const RayGeom g = ray_in_frame(T_fc, x, y, flx, fly, ppx, ppy);
+        const f3 of = g.of, dn = g.dn;
+        const SdfDev &sdf = m.sdfs[s];
+        const float smaxx = sdf.ox + sdf.res * (float)(unsigned)sdf.dimx;
+        const float smaxy = sdf.oy + sdf.res * (float)(unsigned)sdf.dimy;
+        const float smaxz = sdf.oz + sdf.res * (float)(unsigned)sdf.dimz;
+        const float hix = (float)((unsigned)sdf.dimx - 2u), hiy = (float)((unsigned)sdf.dimy - 2u), hiz = (float)((unsigned)sdf.dimz - 2u);
+        float t0, t1;   // intersectBox, raycast.cu:11-35
+        {
+            const float ix = 1.0f / dn.x, iy = 1.0f / dn.y, iz = 1.0f / dn.z;
+            const float bx = ix * (sdf.ox - of.x), by = iy * (sdf.oy - of.y), bz = iz * (sdf.oz - of.z);
+            const float tx = ix * (smaxx - of.x), ty = iy * (smaxy - of.y), tz = iz * (smaxz - of.z);
+            t0 = fmaxf(fmaxf(fminf(tx, bx), fminf(ty, by)), fminf(tz, bz));
+            t1 = fminf(fminf(fmaxf(tx, bx), fmaxf(ty, by)), fmaxf(tz, bz));
+        }
+        float det = 3.0e38f, hit = 0.0f;
+        bool march = t1 > t0;
+        // A crossing needs a sample with value <= levelSet, i.e. a sample inside the SDF's keep box for that level (SdfDev;
+        // samples are clamped to [1, dim-2], so a box side that reaches the clamp planes extends to infinity): a ray that
+        // misses the box is not marched at all -- it could only have ended with "no crossing". Most rays of a tile miss the
+        // few-centimetre link inside its 10 cm padding.
+        if (march && slot >= 0) {
+            const float g0[3] = {(of.x - sdf.ox) / sdf.res, (of.y - sdf.oy) / sdf.res, (of.z - sdf.oz) / sdf.res};
+            const float gd[3] = {dn.x / sdf.res, dn.y / sdf.res, dn.z / sdf.res};
+            const float top[3] = {hix, hiy, hiz};
+            float tin = -3.0e38f, tout = 3.0e38f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float lo = sdf.keepLo[slot][a], hi = sdf.keepHi[slot][a];
+                if (!(lo <= hi)) { tin = 1.0f; tout = 0.0f; break; }        // nothing at or below the level in this SDF
+                const bool openLo = lo <= 1.0f, openHi = hi >= top[a];
+                const float inv = 1.0f / gd[a];
+                float ta = ((lo - 0.05f) - g0[a]) * inv, tb = ((hi + 0.05f) - g0[a]) * inv;
+                if (openLo) ta = (gd[a] > 0) ? -3.0e38f : 3.0e38f;
+                if (openHi) tb = (gd[a] > 0) ? 3.0e38f : -3.0e38f;
+                if (gd[a] == 0.0f) {                                            // parallel to the slab: inside or never
+                    const bool inside = (openLo || g0[a] >= lo - 0.05f) && (openHi || g0[a] <= hi + 0.05f);
+                    ta = inside ? -3.0e38f : 3.0e38f; tb = inside ? 3.0e38f : -3.0e38f;
+                }
+                tin = fmaxf(tin, fminf(ta, tb));
+                tout = fminf(tout, fmaxf(ta, tb));
+            }
+            march = tin <= tout;
+        }
+        if (march) {
+            const float *data = m.grids + sdf.dataOff;
+            // header fields in registers for the march (the compiler does not hoist loads through the SdfDev reference)
+            const float res = sdf.res, rcp = sdf.rcpRes, ox = sdf.ox, oy = sdf.oy, oz = sdf.oz;
+            const bool exactDiv = sdf.divExact != 0;
+            const int dimx = sdf.dimx, dimy = sdf.dimy;
+            auto eval = [&](float tt) -> float {
+                f3 xf, xg;
+                xf.x = dn.x * tt + of.x; xf.y = dn.y * tt + of.y; xf.z = dn.z * tt + of.z;
+                const float dx = xf.x - ox, dy = xf.y - oy, dz = xf.z - oz;
+                if (exactDiv) { xg.x = div_exact(dx, res, rcp); xg.y = div_exact(dy, res, rcp); xg.z = div_exact(dz, res, rcp); }
+                else { xg.x = dx / res; xg.y = dy / res; xg.z = dz / res; }
+                xg.x = fmaxf(1.0f, fminf(xg.x, hix));
+                xg.y = fmaxf(1.0f, fminf(xg.y, hiy));
+                xg.z = fmaxf(1.0f, fminf(xg.z, hiz));
+                return grid_value<CNT_RAYCAST>(data, dimx, dimy, xg) * res;
+            };
+            float sdfValPrev = eval(t0);
+            float tPrev = t0;
 #ifdef DARTK_STAMPS
-        int steps = 0;
+            int steps = 0;
 #endif
-        const float minStep = res / 10;
-#ifdef DARTK_STAMPS
-        // diagnostic build: the same loop with cycle stamps between its three phases (coordinates, load wait, interpolation +
-        // step); the stamps cost ~100 cycles each, so only the split is meaningful
-        unsigned long long cA = 0, cB = 0, cC = 0, passes = 0;
-        const unsigned long long w0 = __builtin_readcyclecounter();
-        while (t0 < t1 && t0 < 10000.0f) {
-            const unsigned long long s0 = __builtin_readcyclecounter();
-            f3 xf, xg;
-            xf.x = dn.x * t0 + of.x; xf.y = dn.y * t0 + of.y; xf.z = dn.z * t0 + of.z;
-            const float dx = xf.x - ox, dy = xf.y - oy, dz = xf.z - oz;
-            if (exactDiv) { xg.x = div_exact(dx, res, rcp); xg.y = div_exact(dy, res, rcp); xg.z = div_exact(dz, res, rcp); }
-            else { xg.x = dx / res; xg.y = dy / res; xg.z = dz / res; }
-            xg.x = fmaxf(1.0f, fminf(xg.x, hix)); xg.y = fmaxf(1.0f, fminf(xg.y, hiy)); xg.z = fmaxf(1.0f, fminf(xg.z, hiz));
-            const float tx = xg.x - 0.5f, ty = xg.y - 0.5f, tz = xg.z - 0.5f;
-            const int x0 = (int)tx, y0 = (int)ty, z0 = (int)tz;
-            const float fx = tx - (float)x0, fy = ty - (float)y0, fz = tz - (float)z0;
-            const float *p = data + (x0 + dimx * (y0 + dimy * z0));
-            asm volatile("" :: "v"(fx), "v"(fy), "v"(fz), "v"(p));
-            const unsigned long long s1 = __builtin_readcyclecounter();
-            const f2u q00 = *reinterpret_cast<const f2u *>(p), q10 = *reinterpret_cast<const f2u *>(p + dimx);
-            const f2u q01 = *reinterpret_cast<const f2u *>(p + dimx * dimy), q11 = *reinterpret_cast<const f2u *>(p + dimx * dimy + dimx);
-            asm volatile("s_waitcnt vmcnt(0)" :: "v"(q00.a), "v"(q10.a), "v"(q01.a), "v"(q11.a) : "memory");
-            const unsigned long long s2 = __builtin_readcyclecounter();
-            const float dx00 = lerpf(q00.a, q00.b, fx), dx01 = lerpf(q01.a, q01.b, fx), dx10 = lerpf(q10.a, q10.b, fx), dx11 = lerpf(q11.a, q11.b, fx);
-            const float sdfVal = lerpf(lerpf(dx00, dx10, fy), lerpf(dx01, dx11, fy), fz) * res;
-            bool crossedNow = false;
-            if (sdfValPrev > levelSet && sdfVal <= levelSet) {
-                det = t0;
-                hit = (t0 - tPrev) * (levelSet - sdfValPrev) / (sdfVal - sdfValPrev) + tPrev;
-                crossedNow = true;
-            } else {
+            const float minStep = res / 10;
+            while (t0 < t1 && t0 < 10000.0f) {      // 10000 = the reference's initial closestT
+                const float sdfVal = eval(t0);
+                if (sdfValPrev > levelSet && sdfVal <= levelSet) {
+                    det = t0;
+                    hit = (t0 - tPrev) * (levelSet - sdfValPrev) / (sdfVal - sdfValPrev) + tPrev;
+                    break;      // the reference's loop ends here too: closestT = hit <= t0 < the next t0
+                }
                 sdfValPrev = sdfVal;
                 tPrev = t0;
                 t0 += fmaxf(minStep, fabsf(sdfVal));
+#ifdef DARTK_STAMPS
                 ++steps;
+#endif
             }
-            asm volatile("" :: "v"(t0), "v"(det));
-            const unsigned long long s3 = __builtin_readcyclecounter();
-            cA += s1 - s0; cB += s2 - s1; cC += s3 - s2; ++passes;
-            if (crossedNow) break;
-        }
-        {
-            const unsigned long long wc = __builtin_readcyclecounter() - w0;
-            const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
-            if (lane == (int)__builtin_ctzll(ex)) {
-                atomicAdd(&g_rayPhase[4], passes); atomicAdd(&g_rayPhase[5], wc);
-                if (atomicMax(&g_rayPhase[0], passes) < passes) {        // (racy among equals: diagnostic only)
-                    g_rayPhase[1] = cA; g_rayPhase[2] = cB; g_rayPhase[3] = cC;
-                }
-            }
-        }
-#else
-        while (t0 < t1 && t0 < 10000.0f) {      // 10000 = the reference's initial closestT
-            const float sdfVal = eval(t0);
-            if (sdfValPrev > levelSet && sdfVal <= levelSet) {
-                det = t0;
-                hit = (t0 - tPrev) * (levelSet - sdfValPrev) / (sdfVal - sdfValPrev) + tPrev;
-                break;      // the reference's loop ends here too: closestT = hit <= t0 < the next t0
-            }
-            sdfValPrev = sdfVal;
-            tPrev = t0;
-            t0 += fmaxf(minStep, fabsf(sdfVal));
 #ifdef DARTK_STAMPS
-            ++steps;
+            atomicMax(&g_rayMaxSteps, steps);
+            atomicAdd(&g_raySteps, (unsigned long long)steps);
+            atomicAdd(&g_rayMarched, 1ull);
 #endif
         }
-#endif
-#ifdef DARTK_STAMPS
-        atomicMax(&g_rayMaxSteps, steps);
-        atomicAdd(&g_raySteps, (unsigned long long)steps);
-        atomicAdd(&g_rayMarched, 1ull);
-#endif
+        count_lookup<CNT_OTHER>();                  // (diagnostic build: trace records written)
+        trace[(size_t)task * 64 + lane] = make_float2(det, hit);
     }
-    trace[(size_t)s * width * height + (x + y * width)] = make_float2(det, hit);
 }
 
 static constexpr int RC_REPLAY_SDFS = 64;    // per-SDF transforms staged in LDS, this many at a time
@@ -226,16 +259,22 @@ __device__ __forceinline__ void replay_stage_transforms(const ModelView &m, int 
 
 // the reference's sequential rule over SDFs [s0, s0+nc) for one pixel: a crossing counts iff it was detected before the
 // closest hit so far
-__device__ __forceinline__ void replay_pixel(float4 &pr, float &closestT, int x, int y, int index, int nPix, int modelNum, int s0, int nc,
+__device__ __forceinline__ void replay_pixel(float4 &pr, float &closestT, int x, int y, int nSdfs, const int *sR, int modelNum, int s0, int nc,
                                              const float *sT, const float2 *__restrict__ trace, float flx, float fly, float ppx, float ppy) {
+    const int tx = x >> 3, ty = y >> 3, sub = (y & 7) * 8 + (x & 7);
     for (int k = 0; k < nc; ++k) {
-        const float2 dh = trace[(size_t)(s0 + k) * nPix + index];
+        const int s = s0 + k;
+        const int rx = tx - sR[s], ry = ty - sR[nSdfs + s], rw = sR[2 * nSdfs + s];
+        const int off = sR[3 * nSdfs + s], cnt = sR[3 * nSdfs + s + 1] - off;
+        // outside the SDF's rectangle nothing was traced: "no crossing"
+        if (rx < 0 || ry < 0 || rx >= rw || ry * rw + rx >= cnt) continue;
+        const float2 dh = trace[(size_t)(off + ry * rw + rx) * 64 + sub];
         if (dh.x < closestT) {
             const float tHit = dh.y;
             const RayGeom g = ray_in_frame(sT + 24 * k, x, y, flx, fly, ppx, ppy);
             const f3 xc = se3_apply_w(sT + 24 * k + 12, g.dn.x * tHit + g.of.x, g.dn.y * tHit + g.of.y, g.dn.z * tHit + g.of.z, 1.0f);
             if (pr.z == 0 || xc.z < pr.z) {
-                pr.x = xc.x; pr.y = xc.y; pr.z = xc.z; pr.w = (float)((modelNum << 16) + s0 + k);
+                pr.x = xc.x; pr.y = xc.y; pr.z = xc.z; pr.w = (float)((modelNum << 16) + s);
             }
             closestT = tHit;
         }
@@ -244,8 +283,10 @@ __device__ __forceinline__ void replay_pixel(float4 &pr, float &closestT, int x,
 
 __global__ void __launch_bounds__(256)
 raycast_replay_kernel(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, ModelView m,
-                      const float2 *__restrict__ trace, float4 *__restrict__ prediction) {
+                      const float2 *__restrict__ trace, float4 *__restrict__ prediction, float levelSet) {
     __shared__ float sT[RC_REPLAY_SDFS * 24];   // T_fc then T_cf per SDF
+    __shared__ int sR[kRectInts];
+    stage_ray_rects(m, levelSet, flx, fly, ppx, ppy, width, height, sR);
     const int nPix = width * height;
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = index < nPix;
@@ -261,7 +302,7 @@ raycast_replay_kernel(float flx, float fly, float ppx, float ppy, int width, int
         __syncthreads();
         replay_stage_transforms(m, s0, nc, sT);
         __syncthreads();
-        if (valid) replay_pixel(pr, closestT, x, y, index, nPix, modelNum, s0, nc, sT, trace, flx, fly, ppx, ppy);
+        if (valid) replay_pixel(pr, closestT, x, y, m.nSdfs, sR, modelNum, s0, nc, sT, trace, flx, fly, ppx, ppy);
     }
     if (valid) prediction[index] = pr;
 }
@@ -280,6 +321,7 @@ raycast_replay_multi_kernel(float flx, float fly, float ppx, float ppy, int widt
                             const float *__restrict__ rayBuf, float4 *__restrict__ prediction, const float4 *__restrict__ obs, int ow,
                             int oh, FrameBatch fb) {
     __shared__ float sT[RC_REPLAY_SDFS * 24];
+    __shared__ int sR[kRectInts];
     const int frame = blockIdx.y;                   // frame of a batch (0 otherwise)
     rayBuf += (size_t)frame * fb.trace;
     prediction += (size_t)frame * fb.pred;
@@ -295,12 +337,14 @@ raycast_replay_multi_kernel(float flx, float fly, float ppx, float ppy, int widt
         select_frame(m, frame);
         const float2 *trace = reinterpret_cast<const float2 *>(rayBuf + a.off[mi]);
         float closestT = 10000;
+        __syncthreads();                            // the previous model's table is no longer read
+        stage_ray_rects(m, 0.0f, flx, fly, ppx, ppy, width, height, sR);
         for (int s0 = 0; s0 < m.nSdfs; s0 += RC_REPLAY_SDFS) {
             const int nc = min(RC_REPLAY_SDFS, m.nSdfs - s0);
             __syncthreads();
             replay_stage_transforms(m, s0, nc, sT);
             __syncthreads();
-            if (valid) replay_pixel(pr, closestT, x, y, index, nPix, mi, s0, nc, sT, trace, flx, fly, ppx, ppy);
+            if (valid) replay_pixel(pr, closestT, x, y, m.nSdfs, sR, mi, s0, nc, sT, trace, flx, fly, ppx, ppy);
         }
     }
     if (valid) {
@@ -315,12 +359,18 @@ raycast_replay_multi_kernel(float flx, float fly, float ppx, float ppy, int widt
 static int launch_raycast_trace(float flx, float fly, float ppx, float ppy, int width, int height, const ModelView &m, float levelSet,
                                 Workspace *ws, hipStream_t st, size_t bufOffset = 0) {
     const size_t nPix = (size_t)width * height;
-    int rc = cur_batch().n > 1 ? DARTK_OK : ensure_ray_buf(ws, bufOffset + 2 * nPix * (size_t)m.nSdfs);     // (callers with an offset / a batch have sized the buffer already)
+    (void)nPix;
+    int rc = cur_batch().n > 1 ? DARTK_OK : ensure_ray_buf(ws, bufOffset + ray_trace_floats(width, height, m.nSdfs));     // (callers with an offset / a batch have sized the buffer already)
     if (rc) return rc;
     const long long tasks = (long long)((width + 7) / 8) * ((height + 7) / 8) * m.nSdfs;
     DARTK_REQUIRE(tasks < (1ll << 31), "ray-cast of %dx%d against %d SDFs exceeds the launch limits", width, height, m.nSdfs);
+    DARTK_REQUIRE(m.nSdfs <= kMaxRaySdfs, "ray-cast supports at most %d SDFs per model, got %d", kMaxRaySdfs, m.nSdfs);
+    // the tasks that survive the tile rectangles are known on the device only: a fixed grid walks them (4 waves per workgroup,
+    // one task per wave and pass); a single frame gets enough workgroups for the whole chip, a batch shares it among its frames
+    const long long want = cur_batch().n > 1 ? 192 : 1024;
+    const unsigned blocks = (unsigned)((tasks + 3) / 4 < want ? (tasks + 3) / 4 : want);
     ProfScope ps(DARTK_PROF_RAYCAST, st);
-    hipLaunchKernelGGL(raycast_trace_kernel, dim3((unsigned)((tasks + 3) / 4), cur_batch().n), dim3(256), 0, st, flx, fly, ppx, ppy, width, height, m,
+    hipLaunchKernelGGL(raycast_trace_kernel, dim3(blocks, cur_batch().n), dim3(256), 0, st, flx, fly, ppx, ppy, width, height, m,
                        (float2 *)(ws->rayBuf + bufOffset), levelSet, cur_batch());
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
@@ -336,7 +386,7 @@ static int launch_raycast(float flx, float fly, float ppx, float ppy, int width,
     const size_t nPix = (size_t)width * height;
     ProfScope ps2(DARTK_PROF_RAYCAST_REPLAY, st);
     hipLaunchKernelGGL(raycast_replay_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height,
-                       modelNum, m, (const float2 *)ws->rayBuf, (float4 *)d_prediction);
+                       modelNum, m, (const float2 *)ws->rayBuf, (float4 *)d_prediction, levelSet);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
@@ -519,10 +569,11 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
     float *rows = sFull + (RED ? NE_BLOCK * fullLd : 0);
     int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ld);
     float *sRT = reinterpret_cast<float *>(waveCnt + 8);       // REPLAY: per-SDF ray transforms, 24 * nSdfs floats
+    int *sR = reinterpret_cast<int *>(sRT + 24 * m.nSdfs);     // REPLAY: the tile rectangles of the sparse traces, 4 * nSdfs + 1 ints
     stage_model(m, sT_fm, sT_mf, nullptr);
     if (REPLAY) {       // nSdfs <= NE_BLOCK checked by the launcher; every thread reads sRT in the first tile already
         replay_stage_transforms(m, 0, m.nSdfs, sRT);
-        __syncthreads();
+        stage_ray_rects(m, 0.0f, ra.flx, ra.fly, ra.ppx, ra.ppy, ra.width, nPix / ra.width, sR);
     }
     float T_gc[12];
 #pragma unroll
@@ -546,7 +597,7 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
                 pc = ra.predOut[index];
                 if (ra.modelNum == 0) { pc.z = 0; pc.w = -1; }
                 float closestT = 10000;
-                replay_pixel(pc, closestT, index % ra.width, index / ra.width, index, nPix, ra.modelNum, 0, m.nSdfs, sRT, ra.trace,
+                replay_pixel(pc, closestT, index % ra.width, index / ra.width, m.nSdfs, sR, ra.modelNum, 0, m.nSdfs, sRT, ra.trace,
                              ra.flx, ra.fly, ra.ppx, ra.ppy);
                 ra.predOut[index] = pc;
             } else {
@@ -685,7 +736,7 @@ int gn_launch_raycast_trace_at(float flx, float fly, float ppx, float ppy, int w
     Workspace *ws;
     int rc = get_workspace(&ws);
     if (rc) return rc;
-    DARTK_REQUIRE((cur_batch().n - 1) * cur_batch().trace + bufOffset + 2 * (size_t)width * height * m.nSdfs <= ws->rayFloats, "trace buffer was not reserved");
+    DARTK_REQUIRE((cur_batch().n - 1) * cur_batch().trace + bufOffset + ray_trace_floats(width, height, m.nSdfs) <= ws->rayFloats, "trace buffer was not reserved");
     return launch_raycast_trace(flx, fly, ppx, ppy, width, height, m, 0.0f, ws, st, bufOffset);
 }
 int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float ppy, int width, int height, int nModels,
@@ -714,7 +765,7 @@ int gn_launch_raycast_replay_at(float flx, float fly, float ppx, float ppy, int 
     const size_t nPix = (size_t)width * height;
     ProfScope ps2(DARTK_PROF_RAYCAST_REPLAY, st);
     hipLaunchKernelGGL(raycast_replay_kernel, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, st, flx, fly, ppx, ppy, width, height,
-                       modelNum, m, (const float2 *)(ws->rayBuf + bufOffset), (float4 *)d_prediction);
+                       modelNum, m, (const float2 *)(ws->rayBuf + bufOffset), (float4 *)d_prediction, 0.0f);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
@@ -739,7 +790,7 @@ int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int
     if (rc) return rc;
     if (beforeNe) DARTK_HIP(hipStreamWaitEvent(st, beforeNe, 0));
     const int d = 6 + m.nJoints, S = sys_size(d), nPix = width * height;
-    const size_t ldsBytes = ne_mod2obs_lds_bytes(m, d, 0) + sizeof(float) * 24 * (size_t)m.nSdfs;
+    const size_t ldsBytes = ne_mod2obs_lds_bytes(m, d, 0) + sizeof(float) * (28 * (size_t)m.nSdfs + 1);
     DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
     const ReplayArgs ra = {flx, fly, ppx, ppy, width, modelNum, (const float2 *)ws->rayBuf, (float4 *)d_prediction};
     ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);

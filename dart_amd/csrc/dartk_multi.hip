@@ -265,7 +265,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     const int tabStride = 36 * n;
     FrameBatch fb = {nFrames, DARTK_MAX_MODELS, (int)sysFloats, tabStride, (size_t)nPix, (size_t)nPred, 0, (size_t)nPix};
     size_t traceOff[DARTK_MAX_MODELS], traceFloats = 0;         // every model's slice of a frame's ray-cast trace buffer
-    for (int m = 0; m < n; ++m) { traceOff[m] = traceFloats; traceFloats += 2 * (size_t)nPred * mods[m]->v.nSdfs; }
+    for (int m = 0; m < n; ++m) { traceOff[m] = traceFloats; traceFloats += ray_trace_floats(o->predWidth, o->predHeight, mods[m]->v.nSdfs); }
     fb.trace = traceFloats;
     if (!batch) fb = FrameBatch{1, 0, 0, 0, 0, 0, 0, 0};
 
