@@ -35,6 +35,7 @@ struct SdfDev {               // 64 bytes
     // of the association (threshold test), the intersection terms (r < 0) or the contact priors (|err| <= threshold), so
     // it is skipped: identical results, far fewer gathers than the reference's padded grids imply (padding 10 cm).
     float keepLo[4][3], keepHi[4][3];       // keep iff keepLo <= g < keepHi on every axis
+    int nbx, nby;             // bricks per row / per slab (brick layout only, see DARTK_SDF_LAYOUT)
 };
 static constexpr int kSdfWords = (int)(sizeof(SdfDev) / 4);
 static_assert(sizeof(SdfDev) % 4 == 0, "SdfDev is copied word by word");
@@ -80,6 +81,26 @@ struct Model {        // host-side handle (dartk_model_t)
     float *dtTmp;     // obs-SDF distance transform scratch (generateObsSdf)
     bool uniformRes;  // all SDFs share one resolution
 };
+
+// ---- storage layout of the model SDFs in HBM (the reference: dense, x fastest, grid_3d.h:82-84) ---------------------------
+//   0  dense: data[x + dimx*(y + dimy*z)]; a trilinear lookup is four 8-byte loads on four rows dimx*4 / dimx*dimy*4 bytes apart
+//   1  4x4x4 bricks with a one-voxel apron: brick (bx,by,bz) stores voxels [4b, 4b+4] per axis as 5x5x5 floats in a 512-byte
+//      slot; the eight corners of any lookup lie in ONE brick (four 8-byte loads within 512 contiguous bytes); 2x the memory
+//   2  one 32-byte record per cell: the eight corners of cell (x0,y0,z0) side by side, one aligned 32-byte fetch; 8x the memory
+// Values and interpolation arithmetic are identical in all three (bit-exact results); chosen at build time, measured in
+// DESIGN.md "SDF layout".
+#ifndef DARTK_SDF_LAYOUT
+#define DARTK_SDF_LAYOUT 1      // measured equal to 0 and 2 within noise (profiles/r02_sdf_layouts.txt); 1 is the layout north_star names
+#endif
+inline size_t sdf_layout_floats(int dx, int dy, int dz) {
+#if DARTK_SDF_LAYOUT == 1
+    return (size_t)((dx + 3) / 4) * ((dy + 3) / 4) * ((dz + 3) / 4) * 128;
+#elif DARTK_SDF_LAYOUT == 2
+    return (size_t)dx * dy * dz * 8;
+#else
+    return (size_t)dx * dy * dz;
+#endif
+}
 
 // ---- error handling -------------------------------------------------------------------------------
 void set_error(const char *fmt, ...);
@@ -289,14 +310,57 @@ __device__ __forceinline__ f3 grid_gradient(const float *__restrict__ data, int 
     return r;
 }
 
-// lookups in one of a model's SDFs (grids = the model's grid arena)
+// lookups in one of a model's SDFs (grids = the model's grid arena), in the build's storage layout (DARTK_SDF_LAYOUT below):
+// the VALUES and the interpolation arithmetic are those of grid_value(); only where the eight corners are fetched from differs
+template <int CAT = CNT_OTHER>
+__device__ __forceinline__ float sdf_lookup(const float *__restrict__ data, int dimx, int dimy, int nbx, int nby, f3 g) {
+#if DARTK_SDF_LAYOUT == 0
+    (void)nbx; (void)nby;
+    return grid_value<CAT>(data, dimx, dimy, g);
+#else
+    count_lookup<CAT>();
+    const float tx = g.x - 0.5f, ty = g.y - 0.5f, tz = g.z - 0.5f;
+    const int x0 = (int)tx, y0 = (int)ty, z0 = (int)tz;
+    const float fx = tx - (float)x0, fy = ty - (float)y0, fz = tz - (float)z0;
+#if DARTK_SDF_LAYOUT == 1
+    (void)dimx; (void)dimy;
+    const float *p = data + (size_t)(((z0 >> 2) * nby + (y0 >> 2)) * nbx + (x0 >> 2)) * 128 + ((x0 & 3) + 5 * ((y0 & 3) + 5 * (z0 & 3)));
+    const f2u q00 = *reinterpret_cast<const f2u *>(p), q10 = *reinterpret_cast<const f2u *>(p + 5);
+    const f2u q01 = *reinterpret_cast<const f2u *>(p + 25), q11 = *reinterpret_cast<const f2u *>(p + 30);
+    const float v000 = q00.a, v100 = q00.b, v010 = q10.a, v110 = q10.b, v001 = q01.a, v101 = q01.b, v011 = q11.a, v111 = q11.b;
+#else
+    (void)nbx; (void)nby;
+    const float4 *p = reinterpret_cast<const float4 *>(data) + 2 * (size_t)(x0 + dimx * (y0 + dimy * z0));
+    const float4 lo = p[0], hi = p[1];
+    const float v000 = lo.x, v100 = lo.y, v010 = lo.z, v110 = lo.w, v001 = hi.x, v101 = hi.y, v011 = hi.z, v111 = hi.w;
+#endif
+    const float dx00 = lerpf(v000, v100, fx);
+    const float dx01 = lerpf(v001, v101, fx);
+    const float dx10 = lerpf(v010, v110, fx);
+    const float dx11 = lerpf(v011, v111, fx);
+    const float dxy0 = lerpf(dx00, dx10, fy);
+    const float dxy1 = lerpf(dx01, dx11, fy);
+    return lerpf(dxy0, dxy1, fz);
+#endif
+}
 template <int CAT = CNT_OTHER>
 __device__ __forceinline__ float sdf_value(const float *__restrict__ grids, const SdfDev &s, f3 g) {
-    return grid_value<CAT>(grids + s.dataOff, s.dimx, s.dimy, g);
+    return sdf_lookup<CAT>(grids + s.dataOff, s.dimx, s.dimy, s.nbx, s.nby, g);
 }
 template <int CAT = CNT_OTHER>
 __device__ __forceinline__ f3 sdf_gradient(const float *__restrict__ grids, const SdfDev &s, f3 g) {
-    return grid_gradient<CAT>(grids + s.dataOff, s.dimx, s.dimy, g);
+    const float *data = grids + s.dataOff;
+    f3 q, r;
+    q = g; q.x = g.x + 1.0f; const float fpx = sdf_lookup<CAT>(data, s.dimx, s.dimy, s.nbx, s.nby, q);
+    q = g; q.y = g.y + 1.0f; const float fpy = sdf_lookup<CAT>(data, s.dimx, s.dimy, s.nbx, s.nby, q);
+    q = g; q.z = g.z + 1.0f; const float fpz = sdf_lookup<CAT>(data, s.dimx, s.dimy, s.nbx, s.nby, q);
+    q = g; q.x = g.x - 1.0f; const float fmx = sdf_lookup<CAT>(data, s.dimx, s.dimy, s.nbx, s.nby, q);
+    q = g; q.y = g.y - 1.0f; const float fmy = sdf_lookup<CAT>(data, s.dimx, s.dimy, s.nbx, s.nby, q);
+    q = g; q.z = g.z - 1.0f; const float fmz = sdf_lookup<CAT>(data, s.dimx, s.dimy, s.nbx, s.nby, q);
+    r.x = 0.5f * (fpx - fmx);
+    r.y = 0.5f * (fpy - fmy);
+    r.z = 0.5f * (fpz - fmz);
+    return r;
 }
 
 // ---- articulated Jacobian (kernel_common.h:12-71) ---------------------------------------------------

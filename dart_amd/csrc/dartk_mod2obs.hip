@@ -199,7 +199,7 @@ raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int 
             // header fields in registers for the march (the compiler does not hoist loads through the SdfDev reference)
             const float res = sdf.res, rcp = sdf.rcpRes, ox = sdf.ox, oy = sdf.oy, oz = sdf.oz;
             const bool exactDiv = sdf.divExact != 0;
-            const int dimx = sdf.dimx, dimy = sdf.dimy;
+            const int dimx = sdf.dimx, dimy = sdf.dimy, nbx = sdf.nbx, nby = sdf.nby;
             auto eval = [&](float tt) -> float {
                 f3 xf, xg;
                 xf.x = dn.x * tt + of.x; xf.y = dn.y * tt + of.y; xf.z = dn.z * tt + of.z;
@@ -209,7 +209,7 @@ raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int 
                 xg.x = fmaxf(1.0f, fminf(xg.x, hix));
                 xg.y = fmaxf(1.0f, fminf(xg.y, hiy));
                 xg.z = fmaxf(1.0f, fminf(xg.z, hiz));
-                return grid_value<CNT_RAYCAST>(data, dimx, dimy, xg) * res;
+                return sdf_lookup<CNT_RAYCAST>(data, dimx, dimy, nbx, nby, xg) * res;
             };
             float sdfValPrev = eval(t0);
             float tPrev = t0;

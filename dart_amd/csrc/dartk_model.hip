@@ -330,9 +330,10 @@ int dartk_model_create(const dartk_model_desc *d, dartk_model_t *out) {
         g.ox = d->sdf_offset[3 * s]; g.oy = d->sdf_offset[3 * s + 1]; g.oz = d->sdf_offset[3 * s + 2];
         g.res = d->sdf_resolution[s];
         g.dataOff = (int)gridFloats;
+        g.nbx = (g.dimx + 3) / 4; g.nby = (g.dimy + 3) / 4;
         fill_bounds(g);
         fill_keep_boxes(g, d->sdf_data[s]);
-        gridFloats = align_up(gridFloats + (size_t)g.dimx * g.dimy * g.dimz, 64);
+        gridFloats = align_up(gridFloats + sdf_layout_floats(g.dimx, g.dimy, g.dimz), 64);
         DARTK_REQUIRE(gridFloats < (size_t)1 << 31, "SDF arena exceeds 2^31 voxels");
     }
     off = align_up(o_grids + gridFloats * sizeof(float), 256);
@@ -376,8 +377,29 @@ int dartk_model_create(const dartk_model_desc *d, dartk_model_t *out) {
         }
     }
     for (int s = 0; s < nS; ++s) {
-        const size_t n = (size_t)sdfs[s].dimx * sdfs[s].dimy * sdfs[s].dimz;
-        memcpy(h.data() + o_grids + sizeof(float) * sdfs[s].dataOff, d->sdf_data[s], n * sizeof(float));
+        const int dx = sdfs[s].dimx, dy = sdfs[s].dimy, dz = sdfs[s].dimz;
+        const float *src = d->sdf_data[s];
+        float *dst = reinterpret_cast<float *>(h.data() + o_grids) + sdfs[s].dataOff;
+        auto at = [&](int x, int y, int z) {      // voxels beyond the grid are never part of a lookup the bound tests admit
+            x = x < dx ? x : dx - 1; y = y < dy ? y : dy - 1; z = z < dz ? z : dz - 1;
+            return src[x + (size_t)dx * (y + (size_t)dy * z)];
+        };
+#if DARTK_SDF_LAYOUT == 1
+        const int nbx = sdfs[s].nbx, nby = sdfs[s].nby, nbz = (dz + 3) / 4;
+        for (int bz = 0; bz < nbz; ++bz) for (int by = 0; by < nby; ++by) for (int bx = 0; bx < nbx; ++bx) {
+            float *b = dst + (size_t)((bz * nby + by) * nbx + bx) * 128;
+            for (int lz = 0; lz < 5; ++lz) for (int ly = 0; ly < 5; ++ly) for (int lx = 0; lx < 5; ++lx)
+                b[lx + 5 * (ly + 5 * lz)] = at(4 * bx + lx, 4 * by + ly, 4 * bz + lz);
+        }
+#elif DARTK_SDF_LAYOUT == 2
+        for (int z = 0; z < dz; ++z) for (int y = 0; y < dy; ++y) for (int x = 0; x < dx; ++x) {
+            float *c = dst + 8 * (x + (size_t)dx * (y + (size_t)dy * z));
+            for (int k = 0; k < 8; ++k) c[k] = at(x + (k & 1), y + ((k >> 1) & 1), z + (k >> 2));
+        }
+#else
+        (void)at;
+        memcpy(dst, src, (size_t)dx * dy * dz * sizeof(float));
+#endif
     }
     DARTK_HIP(hipMemcpy(m->arena, h.data(), total, hipMemcpyHostToDevice));
     (void)staticBytes;
