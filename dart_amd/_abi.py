@@ -152,6 +152,10 @@ def _load(path):
     L = C.CDLL(path)
     L.dartk_last_error.restype = C.c_char_p
     L.dartk_model_obs_sdf_data.restype = C.c_void_p
+    for g in ("T_mf", "T_fm", "T_mc", "sdf_frames", "sdfs", "frame_parents", "joint_types", "joint_axes"):
+        fn = getattr(L, "dartk_model_device_" + g)
+        fn.restype, fn.argtypes = C.c_void_p, [C.c_void_p]
+    L.dartk_model_from_device_pointer.restype, L.dartk_model_from_device_pointer.argtypes = C.c_void_p, [C.c_void_p]
     vp = C.c_void_p
     sigs = {
         "dartk_init": [C.c_int],
@@ -172,6 +176,9 @@ def _load(path):
         "dartk_model_obs_sdf_data": [vp],
         "dartk_assoc_single": [vp, vp, C.c_int, C.c_int, vp, C.c_float, C.c_float, C.c_float, c_float_p, vp, vp, c_int_p, vp, vp, vp, vp],
         "dartk_assoc_multi": [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), c_float_p, c_float_p, c_float_p, C.POINTER(vp), vp, vp, vp, vp],
+        "dartk_assoc_multi_tables": [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "dartk_raycast_prediction_tables": [C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, c_float_p, vp, vp, vp, vp, C.c_int, vp, C.c_float, vp],
+        "dartk_count_self_intersections_tables": [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, c_int_p],
         "dartk_ne_obs2mod": [C.c_int, vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp],
         "dartk_ne_obs2mod_noalloc": [C.c_int, vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp],
         "dartk_ne_obs2mod_reduced": [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp],

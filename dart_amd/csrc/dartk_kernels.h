@@ -31,6 +31,8 @@ struct BatchScope {         // sets the current batch for a scope
 };
 
 int ensure_partials(Workspace *w, size_t floats);
+void registry_add(Model *m);           // dartk_tables.hip: live model handles by their device arrays
+void registry_remove(Model *m);
 int noalloc_scratch(float **out);      // dartk_obs2mod.hip: device address of the no-allocation entry point's scratch array
 int get_multi_args_buffer(void **d_ptr, size_t bytes);
 int ensure_ray_buf(Workspace *w, size_t floats);

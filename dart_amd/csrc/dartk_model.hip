@@ -344,6 +344,16 @@ int dartk_model_create(const dartk_model_desc *d, dartk_model_t *out) {
 
     Model *m = new Model();
     memset(m, 0, sizeof(Model));
+    struct CreateGuard {        // a failure below frees what was built so far
+        Model *m; bool done;
+        ~CreateGuard() {
+            if (done) return;
+            if (m->dtTmp) (void)hipFree(m->dtTmp);
+            if (m->h_pin) (void)hipHostFree(m->h_pin);
+            if (m->arena) (void)hipFree(m->arena);
+            delete m;
+        }
+    } guard{m, false};
     DARTK_HIP(hipGetDevice(&m->device));
     DARTK_HIP(hipMalloc(&m->arena, total));
     m->arenaBytes = total;
@@ -433,6 +443,8 @@ int dartk_model_create(const dartk_model_desc *d, dartk_model_t *out) {
     for (int s = 1; s < nS; ++s) if (d->sdf_resolution[s] != d->sdf_resolution[0]) m->uniformRes = false;
     m->dtTmp = nullptr;
     if (obsVoxels) DARTK_HIP(hipMalloc((void **)&m->dtTmp, obsVoxels * sizeof(float)));
+    guard.done = true;
+    registry_add(m);
     *out = reinterpret_cast<dartk_model_t>(m);
     return DARTK_OK;
 }
@@ -440,6 +452,7 @@ int dartk_model_create(const dartk_model_desc *d, dartk_model_t *out) {
 int dartk_model_destroy(dartk_model_t h) {
     Model *m = reinterpret_cast<Model *>(h);
     if (!m) return DARTK_OK;
+    registry_remove(m);
     if (m->dtTmp) (void)hipFree(m->dtTmp);
     (void)hipHostFree(m->h_pin);
     (void)hipFree(m->arena);

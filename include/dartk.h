@@ -90,6 +90,23 @@ int dartk_model_dims(dartk_model_t m);
 /* device pointer of the observation SDF data (MirroredModel::getDeviceObsSdfData) */
 float *dartk_model_obs_sdf_data(dartk_model_t m);
 
+/* MirroredModel's device getters (mirrored_model.h:65-87: getDeviceTransformsFrameToModel / ...ModelToFrame / getDeviceSdfFrames /
+ * getDeviceSdfs / getDeviceFrameParents / getDeviceJointTypes / getDeviceJointAxes): the library's own device arrays, for
+ * host code that collects them into per-model pointer tables (tracker.cpp:238-243) and hands those to the kernels. SE3 arrays
+ * have the reference layout (12 floats per frame); the SDF table is the library's own header type (opaque to host code, as
+ * Grid3D<float>* is in the reference: it only ever travels back into kernels). */
+const float *dartk_model_device_T_mf(dartk_model_t m);
+const float *dartk_model_device_T_fm(dartk_model_t m);
+const float *dartk_model_device_T_mc(dartk_model_t m);
+const int32_t *dartk_model_device_sdf_frames(dartk_model_t m);
+const void *dartk_model_device_sdfs(dartk_model_t m);
+const int32_t *dartk_model_device_frame_parents(dartk_model_t m);
+const int32_t *dartk_model_device_joint_types(dartk_model_t m);
+const float *dartk_model_device_joint_axes(dartk_model_t m);
+/* The live model that owns a device array returned by one of the getters above (NULL if none): lets an entry point that
+ * receives raw arrays recover the handle. */
+dartk_model_t dartk_model_from_device_pointer(const void *d_ptr);
+
 /* ------------------------------------------------------------------ obs -> mod (kernels/obsToMod.h) */
 /* errorAndDataAssociation, obsToMod.h:75-86 / obsToMod.cu:504-555. Zeroes *d_last, appends associated points,
  * copies the count to *h_last (blocking, like the reference) when h_last != NULL. Debug maps may be NULL. */
@@ -104,6 +121,16 @@ int dartk_assoc_multi(const float *d_vert, const float *d_norm, int width, int h
                       const dartk_model_t *models, const float *h_distThresholds, const float *h_planeOffsets,
                       const float *h_planeNormals3, dartk_da_point *const *h_pts_table, int32_t *d_last,
                       int32_t *d_dbgDA, float *d_dbgErr, void *stream);
+/* errorAndDataAssociationMultiModel with the reference's OWN argument list (obsToMod.h:88-107; call-site optimizer.cpp:620-630):
+ * every pointer is a device pointer, the per-model tables (T_fms, sdfFrames, sdfs, pts) are device arrays of device pointers
+ * built from the getters above. The handles are recovered from T_fms[m]; T_mcs[m] (optimizer.cpp:603-608) becomes the model's
+ * camera->model transform. sdfFrames / sdfs / nSdfs / normalThresholds / dDebugNorm are accepted and not read (the reference
+ * kernel does not read the last two either, SURVEY A-20). Blocking (small device->host copies of the tables). */
+int dartk_assoc_multi_tables(const float *d_vert, const float *d_norm, int width, int height, int nModels, const float *d_T_mcs,
+                             const void *const *d_T_fms, const void *const *d_sdfFrames, const void *const *d_sdfs,
+                             const int32_t *d_nSdfs, const float *d_distanceThresholds, const float *d_normalThresholds,
+                             const float *d_planeOffsets, const float *d_planeNormals3, int32_t *d_lastElements,
+                             dartk_da_point *const *d_pts, int32_t *d_dbgDA, float *d_dbgErr, float *d_dbgNorm, void *stream);
 /* normEqnsObsToMod, obsToMod.h:12-21 / obsToMod.cu:621-697 (system zeroed; kernel only if nElements > 10). */
 int dartk_ne_obs2mod(int dims, const float *d_vert, int width, int height, dartk_model_t m, float huberDelta,
                      const dartk_da_point *d_pts, int nElements, float *d_result, void *stream);
@@ -129,6 +156,11 @@ int dartk_ne_obs2mod_parammap(int dims, int redDims, const int32_t *d_mapping, c
 /* raycastPrediction, raycast.cu:440-466 (one call per model; modelNum 0 clears the map). */
 int dartk_raycast_prediction(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum,
                              dartk_model_t m, float *d_prediction, float levelSet, void *stream);
+/* raycastPrediction with the reference's own argument list (raycast.h:9-22; call-site prediction_renderer.cpp:195-207): T_mc by
+ * value (host), the model's device arrays from the getters above. The handle is recovered from T_fms. */
+int dartk_raycast_prediction_tables(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum,
+                                    const float *h_T_mc, const void *d_T_fms, const void *d_T_mfs, const void *d_sdfFrames,
+                                    const void *d_sdfs, int nSdfs, float *d_prediction, float levelSet, void *stream);
 /* cullUnobservable_, modToObs.cu:1050-1064 */
 int dartk_cull_unobservable(float *d_pred, int predWidth, int predHeight, const float *d_obsVert, int obsWidth,
                             int obsHeight, void *stream);
@@ -186,6 +218,11 @@ int dartk_count_self_intersections(const float *d_sites, int nSites, dartk_model
                                    const int32_t *d_potentialIntersection, int32_t *h_count, void *stream);
 int dartk_count_intersections(const float *d_sites, int nSites, const float *h_T_ds, dartk_model_t src,
                               dartk_model_t dst, int32_t *h_count, void *stream);
+/* countSelfIntersections with the reference's own argument list (intersection.h:11-18): raw device arrays, handle recovered
+ * from T_mfs; blocking, returns the count in *h_count. */
+int dartk_count_self_intersections_tables(const float *d_sites, int nSites, const void *d_T_mfs, const void *d_T_fms,
+                                          const void *d_sdfFrames, const void *d_sdfs, int nSdfs,
+                                          const int32_t *d_potentialIntersection, int32_t *h_count);
 
 /* ---- model / asset pipeline: solid-mesh voxel splat (mesh/mesh_splat.cpp:10-265, splatSolidMesh) -------------------
  * Sets d_sdf[x + y*dimX + z*dimX*dimY] = 0 for every voxel that at least two of the three axis-parallel parity ray
