@@ -70,6 +70,12 @@ class MultiOptionsC(C.Structure):
                 ("predFl", C.c_float * 2), ("lambdaIntersection", C.c_float * 64)]
 
 
+class ReductionC(C.Structure):
+    """dartk_reduction (include/dartk.h)"""
+    _fields_ = [("type", C.c_int32), ("redArtDims", C.c_int32), ("h_A", C.POINTER(C.c_float)), ("h_map", C.POINTER(C.c_int32)),
+                ("h_b", C.POINTER(C.c_float)), ("h_redMin", C.POINTER(C.c_float)), ("h_redMax", C.POINTER(C.c_float))]
+
+
 class NoObsOptions(C.Structure):
     """dartk_noobs_options (include/dartk.h); orc_noobs_options has the same layout."""
     _fields_ = [("numIterations", C.c_int32), ("nModels", C.c_int32), ("regularization", C.c_float * 8),
@@ -207,6 +213,8 @@ def _load(path):
         "dartk_prediction_to_depth": [vp, vp, C.c_int, C.c_int, vp],
         "dartk_noobs_create": [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(vp), c_float_p,
                                C.POINTER(ContactPriorC), C.c_int, C.c_int, C.POINTER(vp)],
+        "dartk_noobs_create_reduced": [C.c_int, C.POINTER(vp), C.POINTER(ReductionC), C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(vp), c_float_p,
+                                       C.POINTER(ContactPriorC), C.c_int, C.c_int, C.POINTER(vp)],
         "dartk_noobs_destroy": [vp],
         "dartk_noobs_set_priors": [vp, C.POINTER(ContactPriorC), C.c_int, vp],
         "dartk_noobs_set_point_priors": [vp, C.POINTER(PointPriorC), C.c_int, vp],

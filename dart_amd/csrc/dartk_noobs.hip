@@ -49,6 +49,15 @@ struct NoObsProblem {            // device-visible description shared by both ke
     int poseOff[DARTK_MAX_MODELS];   // offset of model m's pose block inside a candidate's pose record
     int jointOff[DARTK_MAX_MODELS];
     int uniformRes[DARTK_MAX_MODELS];   // 1 when all SDFs of the model share one resolution
+    // pose reductions (pose.h; optimizer.cpp:841-846, 933-954): dims[] above are the REDUCED dimensions 6 + redArt[]; a
+    // candidate's pose record carries the reduced articulation behind its transforms (rebase / red_art below)
+    int redType[DARTK_MAX_MODELS];      // 0 null, 1 linear, 2 parameter map
+    int redArt[DARTK_MAX_MODELS];       // reduced articulation dimensions (the joint count for type 0)
+    const float *redA[DARTK_MAX_MODELS];        // [nJoints][redArt] first derivatives (types 1 and 2)
+    const int *redMap[DARTK_MAX_MODELS];        // [nJoints] (type 2)
+    const float *redB[DARTK_MAX_MODELS];        // [nJoints] offsets
+    const float *redMin[DARTK_MAX_MODELS], *redMax[DARTK_MAX_MODELS];     // [redArt]
+    int anyReduced, maxFullDims;
     ModelView model[DARTK_MAX_MODELS];   // static tables only; pose pointers are rebased per candidate
     NoObsTerm term[NOOBS_MAX_TERMS];
     const dartk_contact_prior *priors;
@@ -93,6 +102,17 @@ __device__ __forceinline__ ModelView rebase(const ModelView &s, float *pose) {
     return v;
 }
 static int pose_block_floats(const ModelView &m) { return 24 + (m.nJoints > 0 ? m.nJoints : 1) + 24 * m.nFrames; }
+// a reduced model's record continues with its reduced articulation [redArt]
+__host__ __device__ inline int red_art_offset(const ModelView &m) { return 24 + (m.nJoints > 0 ? m.nJoints : 1) + 24 * m.nFrames; }
+
+// full joint vector from the reduced articulation (pose.cpp:66-73 linear, :91-97 parameter map); lane f = joint f
+__device__ __forceinline__ float project_joint(const NoObsProblem *P, int mi, const float *red, int f) {
+    if (P->redType[mi] == 2) return red[P->redMap[mi][f]];
+    const int nr = P->redArt[mi];
+    float full = P->redB[mi][f];
+    for (int r = 0; r < nr; ++r) full = full + red[r] * P->redA[mi][r + f * nr];
+    return full;
+}
 
 // import poses (T_mc, joints) of the batch into the pose array and run forward kinematics; grid (model, candidate)
 __global__ void __launch_bounds__(64)
@@ -104,7 +124,14 @@ noobs_load_poses_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ 
     const ModelView m = rebase(P->model[mi], pose);
     const int lane = threadIdx.x;
     if (lane < 12) pose[lane] = T_mcs[((size_t)c * P->nModels + mi) * 12 + lane];
-    if (lane < m.nJoints) m.joints[lane] = joints[(size_t)c * P->jointStride + P->jointOff[mi] + lane];
+    const float *jin = joints + (size_t)c * P->jointStride + P->jointOff[mi];
+    if (P->redType[mi] == 0) {
+        if (lane < m.nJoints) m.joints[lane] = jin[lane];
+    } else {        // the caller's array holds the reduced articulation: keep it, project it (Pose::projectReducedToFull)
+        float *red = pose + red_art_offset(m);
+        if (lane < P->redArt[mi]) red[lane] = jin[lane];
+        if (lane < m.nJoints) m.joints[lane] = project_joint(P, mi, jin, lane);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (lane == 0) {
@@ -190,6 +217,9 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     float *rows = lds + sSdfOff[nModels];
     int *waveCnt = reinterpret_cast<int *>(rows + NOOBS_ROWS * ld);
     int *sPot = waveCnt + 8;            // the self term's potential-intersection matrix (when it fits)
+    // reduced poses: scratch for the full Jacobian of a parked point before its reduction (one row per parked point)
+    const int fullLd = P->maxFullDims | 1;
+    float *sFullJ = reinterpret_cast<float *>(sPot + (TYPE == TERM_SELF ? potLdsInts : 0));
     ModelView src = rebase(P->model[T.src], poseC + P->poseOff[T.src]);
     ModelView dst = rebase(P->model[T.dst], poseC + P->poseOff[T.dst]);
     src.sdfs = sSdf(T.src); src.sdfFrame = sFrm(T.src, src.nSdfs);
@@ -239,14 +269,17 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                 float *L = row + lOff;
                 const ModelView &ms = P->model[pSrc];
                 const ModelView &md = P->model[pDst];
+                // The priors index the model's Jacobian by the pose's REDUCED dimensions (contact_prior.cpp:31-32,110-126:
+                // subJ(i) = dot(grad, J3D[i]) for i < getReducedDimensions(), J3D being the FULL Jacobian): for a reduced pose
+                // that is the first 6 + redArt columns of the full Jacobian, kept as the reference computes it
                 if (upSrc)
-                    error_jacobian<false>(L + P->off[pSrc], pm, 1.0f, ms.depMask[srcFrame], gs, ms.nJoints, ms.jointType, ms.jointAxis,
+                    error_jacobian<false>(L + P->off[pSrc], pm, 1.0f, ms.depMask[srcFrame], gs, P->dims[pSrc] - 6, ms.jointType, ms.jointAxis,
                                           sTf(pSrc), sTf(pSrc) + 12 * ms.nFrames);
                 if (upDst) {
                     float *rd = L + P->off[pDst];
-                    error_jacobian<false>(rd, pdm, 1.0f, md.depMask[dstFrame], gdm, md.nJoints, md.jointType, md.jointAxis,
+                    error_jacobian<false>(rd, pdm, 1.0f, md.depMask[dstFrame], gdm, P->dims[pDst] - 6, md.jointType, md.jointAxis,
                                           sTf(pDst), sTf(pDst) + 12 * md.nFrames);
-                    const int nd = 6 + md.nJoints;
+                    const int nd = P->dims[pDst];
                     for (int i = 0; i < nd; ++i) rd[i] = -rd[i];
                 }
                 L[d] = 1.0f;
@@ -255,8 +288,18 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                 for (int i = 0; i < d; ++i) row[2 + i] = weight * L[i];      // (w*J) J^T   (:129)
             } else {
                 for (int i = d + 3; i < ld; ++i) row[i] = 0.0f;
-                error_jacobian<TYPE == TERM_SELF>(row + 2, pm, 1.0f, src.depMask[packed], gs, src.nJoints, src.jointType, src.jointAxis,
-                                                  sTf(T.src), sTf(T.src) + 12 * src.nFrames);
+                const int red = P->redType[T.src];
+                if (red == 0) {
+                    error_jacobian<TYPE == TERM_SELF>(row + 2, pm, 1.0f, src.depMask[packed], gs, src.nJoints, src.jointType, src.jointAxis,
+                                                      sTf(T.src), sTf(T.src) + 12 * src.nFrames);
+                } else {        // normEqns*Reduced / *ParamMap (intersection.cu:147-300, 445-597): full Jacobian, then its reduction
+                    float *Jf = sFullJ + threadIdx.x * fullLd;
+                    error_jacobian<TYPE == TERM_SELF>(Jf, pm, 1.0f, src.depMask[packed], gs, src.nJoints, src.jointType, src.jointAxis,
+                                                      sTf(T.src), sTf(T.src) + 12 * src.nFrames);
+                    const int fullDims = 6 + src.nJoints, redDims = P->dims[T.src];
+                    if (red == 1) reduce_jacobian<1>(row + 2, Jf, TYPE == TERM_SELF ? 0 : 6, fullDims, redDims, P->redA[T.src], nullptr);
+                    else reduce_jacobian<2>(row + 2, Jf, TYPE == TERM_SELF ? 0 : 6, fullDims, redDims, nullptr, P->redMap[T.src]);
+                }
                 row[0] = residual;
                 row[1] = (float)(0.5 * (double)residual * (double)residual);
                 row[d + 2] = 1.0f;
@@ -589,9 +632,20 @@ noobs_solve_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
             se3_invert(Tn, Tinv);
             for (int i = 0; i < 12; ++i) { mv.T_mc[i] = Tn[i]; mv.T_cm[i] = Tinv[i]; }
         }
-        if (lane < mv.nJoints) {
-            const float v = mv.joints[lane] + b[off + 6 + lane];
-            mv.joints[lane] = fminf(fmaxf(mv.limits[2 * lane], v), mv.limits[2 * lane + 1]);
+        if (P->redType[mi] == 0) {
+            if (lane < mv.nJoints) {
+                const float v = mv.joints[lane] + b[off + 6 + lane];
+                mv.joints[lane] = fminf(fmaxf(mv.limits[2 * lane], v), mv.limits[2 * lane + 1]);
+            }
+        } else {        // reduced articulation with its own limits, then Pose::projectReducedToFull (optimizer.cpp:945-952)
+            float *red = poseC + P->poseOff[mi] + red_art_offset(mv);
+            if (lane < P->redArt[mi]) {
+                const float v = red[lane] + b[off + 6 + lane];
+                red[lane] = fminf(fmaxf(P->redMin[mi][lane], v), P->redMax[mi][lane]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane < mv.nJoints) mv.joints[lane] = project_joint(P, mi, red, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         fk_wave(mv, 0, sT);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -605,7 +659,11 @@ __global__ void noobs_store_poses_kernel(const NoObsProblem *__restrict__ P, con
     const float *pose = poses + (size_t)c * P->poseStride + P->poseOff[mi];
     const int lane = threadIdx.x;
     if (lane < 12) T_mcs[((size_t)c * P->nModels + mi) * 12 + lane] = pose[lane];
-    if (lane < P->model[mi].nJoints) joints[(size_t)c * P->jointStride + P->jointOff[mi] + lane] = pose[24 + lane];
+    if (P->redType[mi] == 0) {
+        if (lane < P->model[mi].nJoints) joints[(size_t)c * P->jointStride + P->jointOff[mi] + lane] = pose[24 + lane];
+    } else if (lane < P->redArt[mi]) {
+        joints[(size_t)c * P->jointStride + P->jointOff[mi] + lane] = pose[red_art_offset(P->model[mi]) + lane];
+    }
 }
 
 struct NoObs {
@@ -613,6 +671,7 @@ struct NoObs {
     NoObsProblem *d;           // device copy
     dartk_contact_prior *d_priors;
     dartk_point_prior *d_pointPriors;
+    float *d_redTables;        // reductions: A | b | min | max per model, then the parameter maps
     int nPriors;
     int maxBatch;
     int ldsModels, slabFloats;     // LDS floats of the staged model tables; slab floats per candidate of the fixed terms
@@ -690,6 +749,7 @@ int dartk_noobs_destroy(dartk_noobs_t h) {
     if (t->d) (void)hipFree(t->d);
     if (t->d_priors) (void)hipFree(t->d_priors);
     if (t->d_pointPriors) (void)hipFree(t->d_pointPriors);
+    if (t->d_redTables) (void)hipFree(t->d_redTables);
     if (t->poses) (void)hipFree(t->poses);
     if (t->slabs) (void)hipFree(t->slabs);
     delete t;
@@ -699,6 +759,13 @@ int dartk_noobs_destroy(dartk_noobs_t h) {
 int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *const *d_clouds, const int32_t *nCloudPoints,
                        const int32_t *const *d_potentials, const float *h_lambdaIntersection, const dartk_contact_prior *h_priors,
                        int nPriors, int maxBatch, dartk_noobs_t *out) {
+    return dartk_noobs_create_reduced(nModels, models, nullptr, d_clouds, nCloudPoints, d_potentials, h_lambdaIntersection, h_priors, nPriors,
+                                      maxBatch, out);
+}
+
+int dartk_noobs_create_reduced(int nModels, const dartk_model_t *models, const dartk_reduction *h_red, const float *const *d_clouds,
+                               const int32_t *nCloudPoints, const int32_t *const *d_potentials, const float *h_lambdaIntersection,
+                               const dartk_contact_prior *h_priors, int nPriors, int maxBatch, dartk_noobs_t *out) {
     DARTK_REQUIRE(models && out && h_lambdaIntersection && nCloudPoints && d_clouds && d_potentials, "dartk_noobs_create: null argument");
     DARTK_REQUIRE(nModels >= 1 && nModels <= DARTK_MAX_MODELS, "nModels %d out of range [1,%d]", nModels, DARTK_MAX_MODELS);
     DARTK_REQUIRE(nPriors >= 0 && (nPriors == 0 || h_priors), "bad prior list");
@@ -708,15 +775,56 @@ int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *co
     NoObsProblem &P = t->h;
     P.nModels = nModels; P.nPriors = nPriors;
     int D = 0, poseOff = 0, jointOff = 0, maxFrames = 1;
+    size_t redFloats = 0, redInts = 0;
     for (int m = 0; m < nModels; ++m) {
         Model *mod = reinterpret_cast<Model *>(models[m]);
         if (!mod) { delete t; set_error("dartk_noobs_create: null model %d", m); return DARTK_ERR_INVALID; }
         P.model[m] = mod->v;
-        P.off[m] = D; P.dims[m] = 6 + mod->v.nJoints; D += P.dims[m];
-        P.poseOff[m] = poseOff; poseOff += pose_block_floats(mod->v);
-        P.jointOff[m] = jointOff; jointOff += mod->v.nJoints;
+        const int nJ = mod->v.nJoints;
+        const int type = h_red ? h_red[m].type : 0;
+        const int redArt = type == 0 ? nJ : h_red[m].redArtDims;
+        if (type < 0 || type > 2 || redArt < 0 || redArt > nJ || (type != 0 && (!h_red[m].h_A || !h_red[m].h_redMin || !h_red[m].h_redMax)) ||
+            (type == 2 && !h_red[m].h_map)) {
+            delete t; set_error("dartk_noobs_create: bad pose reduction for model %d", m); return DARTK_ERR_INVALID;
+        }
+        P.redType[m] = type; P.redArt[m] = redArt;
+        if (type != 0) { P.anyReduced = 1; redFloats += (size_t)nJ * redArt + nJ + 2 * (size_t)redArt; redInts += nJ; }
+        if (6 + nJ > P.maxFullDims) P.maxFullDims = 6 + nJ;
+        P.off[m] = D; P.dims[m] = 6 + redArt; D += P.dims[m];
+        P.poseOff[m] = poseOff; poseOff += pose_block_floats(mod->v) + (type != 0 ? redArt : 0);
+        P.jointOff[m] = jointOff; jointOff += redArt;
         if (mod->v.nFrames > maxFrames) maxFrames = mod->v.nFrames;
         P.uniformRes[m] = mod->uniformRes ? 1 : 0;
+    }
+    if (P.anyReduced) {         // one device block: per reduced model A | b | min | max, then the parameter maps
+        std::vector<float> tab(redFloats + redInts);
+        hipError_t e0 = hipMalloc((void **)&t->d_redTables, sizeof(float) * tab.size());
+        if (e0 != hipSuccess) { delete t; set_error("dartk_noobs_create: %s", hipGetErrorString(e0)); return DARTK_ERR_HIP; }
+        size_t o = 0;
+        for (int m = 0; m < nModels; ++m) {
+            if (P.redType[m] == 0) continue;
+            const int nJ = P.model[m].nJoints, nr = P.redArt[m];
+            P.redA[m] = t->d_redTables + o; memcpy(tab.data() + o, h_red[m].h_A, sizeof(float) * (size_t)nJ * nr); o += (size_t)nJ * nr;
+            P.redB[m] = t->d_redTables + o;
+            for (int f = 0; f < nJ; ++f) tab[o + f] = h_red[m].h_b ? h_red[m].h_b[f] : 0.0f;
+            o += nJ;
+            P.redMin[m] = t->d_redTables + o; memcpy(tab.data() + o, h_red[m].h_redMin, sizeof(float) * nr); o += nr;
+            P.redMax[m] = t->d_redTables + o; memcpy(tab.data() + o, h_red[m].h_redMax, sizeof(float) * nr); o += nr;
+        }
+        for (int m = 0; m < nModels; ++m) {
+            if (P.redType[m] == 0) continue;
+            const int nJ = P.model[m].nJoints;
+            P.redMap[m] = reinterpret_cast<const int *>(t->d_redTables + o);
+            int *dst = reinterpret_cast<int *>(tab.data() + o);
+            for (int f = 0; f < nJ; ++f) {
+                const int v = h_red[m].h_map ? h_red[m].h_map[f] : 0;
+                if (P.redType[m] == 2 && (v < 0 || v >= P.redArt[m])) { dartk_noobs_destroy(reinterpret_cast<dartk_noobs_t>(t)); set_error("model %d: parameter map entry %d out of range", m, v); return DARTK_ERR_INVALID; }
+                dst[f] = v;
+            }
+            o += nJ;
+        }
+        e0 = hipMemcpy(t->d_redTables, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice);
+        if (e0 != hipSuccess) { dartk_noobs_destroy(reinterpret_cast<dartk_noobs_t>(t)); set_error("dartk_noobs_create: %s", hipGetErrorString(e0)); return DARTK_ERR_HIP; }
     }
     if (D > 64) { delete t; set_error("global system dimension %d exceeds 64 (one lane per unknown in the solve)", D); return DARTK_ERR_UNSUPPORTED; }
     P.D = D; P.poseStride = poseOff; P.jointStride = jointOff > 0 ? jointOff : 1;
@@ -751,7 +859,8 @@ int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *co
         T.cloud = reinterpret_cast<const float4 *>(cloud); T.pot = pot;
         if (T.S > SMax) SMax = T.S;
         const int ld = noobs_row_len(type, dims);
-        t->ldsTerm[nTerms - 1] = sizeof(float) * ((size_t)ldsModels + (size_t)NOOBS_ROWS * ld + 8 + (type == TERM_SELF ? t->potLdsInts : 0));
+        t->ldsTerm[nTerms - 1] = sizeof(float) * ((size_t)ldsModels + (size_t)NOOBS_ROWS * ld + 8 + (type == TERM_SELF ? t->potLdsInts : 0) +
+                                                  (P.anyReduced && !term_weighted(type) ? (size_t)NOOBS_ROWS * (P.maxFullDims | 1) : 0));
     };
     for (int m = 0; m < nModels; ++m) {
         if (h_lambdaIntersection[m + m * nModels] > 0 && nCloudPoints[m] > 0 && P.dims[m] > 6) {

@@ -130,7 +130,8 @@ class TrackerNoObs:
         self.clouds = []
         self.potentials = []
         self.T_mc = []          # per model, camera->model (Pose::getTransformCameraToModel)
-        self.joints = []
+        self.joints = []        # per model: the joints, or the REDUCED articulation of a model with a pose reduction
+        self.reductions = []    # per model: None | LinearPoseReduction | ParamMapPoseReduction (pose.py)
         self.priors: List[ContactPrior] = []
         self.point_priors: List[Point3D3DPrior] = []      # evaluated after the contact priors (device and oracle alike)
         self.opts = OptimizationOptions()
@@ -142,8 +143,12 @@ class TrackerNoObs:
         self._terms_key = None
 
     # ---- TrackerNoObs::addModel (tracker_no_obs.cpp:58-235): voxelised host model -> device mirror + collision cloud
-    def addModel(self, host_model, collision_cloud_density=1e5, cloud_seed=0):
+    def addModel(self, host_model, collision_cloud_density=1e5, cloud_seed=0, reduction=None):
+        """reduction: a pose.LinearPoseReduction / ParamMapPoseReduction (TrackerNoObs::addModel's poseReduction argument; the
+        Barrett ContactGrasp set-up, grasp_analyzer.cpp:393-420): the optimisation then runs in the reduced dimensions and the
+        model's `joints` entries everywhere in this class are its reduced articulation."""
         m_id = len(self.models)
+        self.reductions.append(None if reduction is None or reduction.isNull() else reduction)
         dm = device.DeviceModel(host_model, model_id=m_id)
         self.models.append(dm)
         self.host_models.append(host_model)
@@ -153,7 +158,7 @@ class TrackerNoObs:
         n = len(host_model.sdfs)
         self.potentials.append(torch.ones(n * n, dtype=torch.int32, device=dev))
         self.T_mc.append(se3.identity())
-        self.joints.append(np.zeros(host_model.n_joints, dtype=F))
+        self.joints.append(np.zeros(host_model.n_joints if self.reductions[-1] is None else self.reductions[-1].getReducedDimensions(), dtype=F))
         n_models = len(self.models)
         # option vectors grow with the models (tracker_no_obs.cpp:219-229)
         old = self.opts.lambdaIntersection
@@ -226,11 +231,47 @@ class TrackerNoObs:
         lam = (C.c_float * (n * n))(*self.opts.lambdaIntersection)
         arr = priors_array(self.priors)
         h = C.c_void_p()
-        check(lib().dartk_noobs_create(n, handles, clouds, counts, pots, lam, arr, len(self.priors), self.max_batch, C.byref(h)))
+        reds, keep = self.reductions_struct(_abi.ReductionC)
+        check(lib().dartk_noobs_create_reduced(n, handles, reds, clouds, counts, pots, lam, arr, len(self.priors), self.max_batch, C.byref(h)))
         self._handle = h
         self._terms_key = key
         self._priors_sig = self._sig()
         self._points_sig = None
+
+    def reductions_struct(self, cls):
+        """Array of dartk_reduction (or the oracle's orc_reduction, same meaning) for the models, or None when none is reduced."""
+        if not any(r is not None for r in self.reductions):
+            return None, []
+        n = len(self.models)
+        arr = (cls * n)()
+        keep = []
+        names = {f[0] for f in cls._fields_}
+        for m, r in enumerate(self.reductions):
+            if r is None:
+                continue
+            A = np.ascontiguousarray(r.getFirstDerivatives(), dtype=F)
+            b = np.ascontiguousarray(r._b, dtype=F)
+            mins = np.asarray([r.getMin(k) for k in range(r.getReducedDimensions())], dtype=F)
+            maxs = np.asarray([r.getMax(k) for k in range(r.getReducedDimensions())], dtype=F)
+            keep += [A, b, mins, maxs]
+            mp = None
+            if r.isParamMap():
+                mp = np.ascontiguousarray(r.getMapping(), dtype=np.int32)
+                keep.append(mp)
+            if "redArtDims" in names:       # dartk_reduction
+                arr[m].type, arr[m].redArtDims = (2 if r.isParamMap() else 1), r.getReducedDimensions()
+                arr[m].h_A, arr[m].h_b, arr[m].h_redMin, arr[m].h_redMax = _abi.fptr(A), _abi.fptr(b), _abi.fptr(mins), _abi.fptr(maxs)
+                if mp is not None:
+                    arr[m].h_map = _abi.iptr(mp)
+            else:                           # orc_reduction (tests)
+                arr[m].type, arr[m].redArt = (2 if r.isParamMap() else 1), r.getReducedDimensions()
+                arr[m].A, arr[m].b, arr[m].mins, arr[m].maxs = _abi.fptr(A), _abi.fptr(b), _abi.fptr(mins), _abi.fptr(maxs)
+                if mp is not None:
+                    arr[m].mapping = _abi.iptr(mp)
+        return arr, keep
+
+    def reduced_dims(self, m):
+        return 6 + (self.host_models[m].n_joints if self.reductions[m] is None else self.reductions[m].getReducedDimensions())
 
     def _sig(self):
         return [(p.weight, tuple(p.contactPoint), p.contactThreshold) for p in self.priors]
@@ -283,7 +324,7 @@ class TrackerNoObs:
         self._sync_priors()
         o = self._options_struct()
         energy = torch.empty(B, dtype=torch.float32, device=dev)
-        D = sum(m.dims for m in self.models)
+        D = sum(self.reduced_dims(m) for m in range(len(self.models)))
         info = first = None
         if debug:
             info = torch.zeros((B, max(o.numIterations, 1), 8), dtype=torch.float32, device=dev)

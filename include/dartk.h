@@ -303,6 +303,24 @@ int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *co
                        const int32_t *nCloudPoints, const int32_t *const *d_potentialIntersection,
                        const float *h_lambdaIntersection, const dartk_contact_prior *h_priors, int nPriors, int maxBatch,
                        dartk_noobs_t *out);
+/* The same with pose reductions (pose.h: NullReduction / LinearPoseReduction / ParamMapPoseReduction; the reference's Barrett
+ * ContactGrasp set-up, grasp_analyzer.cpp:393-420, refines a LinearPoseReduction(8 -> 4) pose): OptimizerNoObs works in the
+ * REDUCED dimensions 6 + redArtDims per model (optimizer.cpp:821-823), the intersection terms use their Reduced / ParamMap forms
+ * (optimizer.cpp:332-421), the update clamps the reduced articulation to the reduction's limits and projects it to the joints
+ * (optimizer.cpp:945-952). h_reductions: [nModels] or NULL (no model reduced). For a reduced model the joint arrays of
+ * dartk_noobs_optimize_poses / _get_error carry its redArtDims reduced values instead of its joints. */
+typedef struct dartk_reduction {
+    int32_t type;                       /* 0 null, 1 linear (full = b + A*reduced, pose.cpp:66-73), 2 parameter map (pose.cpp:91-97) */
+    int32_t redArtDims;                 /* ignored for type 0 */
+    const float *h_A;                   /* types 1, 2: first derivatives [nJoints][redArtDims] (PoseReduction::getFirstDerivatives) */
+    const int32_t *h_map;               /* type 2: [nJoints] */
+    const float *h_b;                   /* type 1: [nJoints] offsets, NULL = zeros */
+    const float *h_redMin, *h_redMax;   /* [redArtDims] */
+} dartk_reduction;
+int dartk_noobs_create_reduced(int nModels, const dartk_model_t *models, const dartk_reduction *h_reductions,
+                               const float *const *d_collisionClouds, const int32_t *nCloudPoints,
+                               const int32_t *const *d_potentialIntersection, const float *h_lambdaIntersection,
+                               const dartk_contact_prior *h_priors, int nPriors, int maxBatch, dartk_noobs_t *out);
 int dartk_noobs_destroy(dartk_noobs_t t);
 /* ContactPrior::setWeight / setContactThreshold / contact point resets (priors.h:66-67, grasp_analyzer.cpp:941-981) */
 int dartk_noobs_set_priors(dartk_noobs_t t, const dartk_contact_prior *h_priors, int nPriors, void *stream);

@@ -118,8 +118,16 @@ void orc_optimize_pose(const orc_model *m, float *T_mc, float *joints, const flo
 /* ------------------------------------------------------------------------------------------------
  * OptimizerNoObs::optimizePoses / getError (optimizer.cpp:783-1076)
  * ---------------------------------------------------------------------------------------------- */
+/* Pose reductions of the NoObs path (grasp_analyzer.cpp:393-420: Barrett's LinearPoseReduction(8 -> 4)); [nModels] or NULL.
+ * With a reduction the joints[m] arrays of orc_optimize_poses_noobs / orc_get_error_noobs carry the REDUCED articulation. */
+static const orc_reduction *g_noobsRed = NULL;
+void orc_noobs_set_reductions(const orc_reduction *red) { g_noobsRed = red; }
+static void project_reduced(const orc_model *m, const orc_reduction *r, const float *art, float *full);
+static int noobs_red_type(int m) { return g_noobsRed ? g_noobsRed[m].type : 0; }
+
 typedef struct {
     int n, D, sys, nPriors;
+    float *full[ORC_MAX_MODELS];     /* full joint vectors (projection of the reduced articulation) */
     int offs[ORC_MAX_MODELS], dims[ORC_MAX_MODELS];
     float *T_mf[ORC_MAX_MODELS], *T_fm[ORC_MAX_MODELS], *T_cm[ORC_MAX_MODELS];
     const float *cT_mc[ORC_MAX_MODELS], *cT_cm[ORC_MAX_MODELS], *cT_fm[ORC_MAX_MODELS], *cT_mf[ORC_MAX_MODELS];
@@ -129,7 +137,9 @@ typedef struct {
 static void noobs_init(noobs_ctx *c, const orc_model *const *models, int n, const orc_contact_prior *priors, int nPriors) {
     c->n = n; c->D = 0; c->nPriors = nPriors;
     for (int m = 0; m < n; ++m) {
-        c->offs[m] = c->D; c->dims[m] = 6 + models[m]->n_joints; c->D += c->dims[m];
+        /* getReducedDimensions(), optimizer.cpp:821-823 */
+        c->offs[m] = c->D; c->dims[m] = 6 + (noobs_red_type(m) ? g_noobsRed[m].redArt : models[m]->n_joints); c->D += c->dims[m];
+        c->full[m] = (float *)calloc((size_t)models[m]->n_joints + 1, sizeof(float));
         c->T_mf[m] = (float *)malloc(sizeof(float) * 12 * (size_t)models[m]->n_frames);
         c->T_fm[m] = (float *)malloc(sizeof(float) * 12 * (size_t)models[m]->n_frames);
         c->T_cm[m] = (float *)malloc(sizeof(float) * 12);
@@ -145,12 +155,14 @@ static void noobs_init(noobs_ctx *c, const orc_model *const *models, int n, cons
     c->sys = sys;
 }
 static void noobs_free(noobs_ctx *c) {
-    for (int m = 0; m < c->n; ++m) { free(c->T_mf[m]); free(c->T_fm[m]); free(c->T_cm[m]); }
+    for (int m = 0; m < c->n; ++m) { free(c->T_mf[m]); free(c->T_fm[m]); free(c->T_cm[m]); free(c->full[m]); }
     free(c->priorOff);
 }
 static void noobs_set_poses(noobs_ctx *c, const orc_model *const *models, float *const *T_mcs, float *const *joints) {
     for (int m = 0; m < c->n; ++m) {
-        orc_fk_set_pose(models[m], joints[m], c->T_mf[m], c->T_fm[m]);
+        /* poses[m].projectReducedToFull(); models[m]->setPose(poses[m])  (optimizer.cpp:841-846) */
+        project_reduced(models[m], g_noobsRed ? &g_noobsRed[m] : NULL, joints[m], c->full[m]);
+        orc_fk_set_pose(models[m], c->full[m], c->T_mf[m], c->T_fm[m]);
         orc_se3_invert(T_mcs[m], c->T_cm[m]);
         c->cT_mc[m] = T_mcs[m]; c->cT_cm[m] = c->T_cm[m]; c->cT_fm[m] = c->T_fm[m]; c->cT_mf[m] = c->T_mf[m];
     }
@@ -161,9 +173,12 @@ static float noobs_intersection_terms(noobs_ctx *c, const orc_model *const *mode
                                       const orc_noobs_options *o, const float *const *clouds, const int32_t *nClouds,
                                       const int32_t *const *potentials, float *eJ, float *JTJ, float *sys) {
     const int n = c->n, dims = c->dims[m], ad = dims - 6;
+    const int redType = noobs_red_type(m);
+    const float *A = redType == 1 ? g_noobsRed[m].A : NULL;
+    const int32_t *map = redType == 2 ? g_noobsRed[m].mapping : NULL;
     float total = 0.0f;
-    if (o->lambdaIntersection[m + m * n] > 0) { /* computeSelfIntersectionContribution, optimizer.cpp:332-384 */
-        orc_ne_self_intersection(clouds[m], nClouds[m], models[m], c->T_fm[m], c->T_mf[m], potentials[m], 0, dims, NULL, NULL, sys);
+    if (o->lambdaIntersection[m + m * n] > 0 && ad > 0) { /* computeSelfIntersectionContribution, optimizer.cpp:332-384 */
+        orc_ne_self_intersection(clouds[m], nClouds[m], models[m], c->T_fm[m], c->T_mf[m], potentials[m], redType, dims, A, map, sys);
         if (ad > 0) {
             float *eJt = (float *)calloc((size_t)ad, sizeof(float));
             float *Jt = (float *)calloc((size_t)ad * ad, sizeof(float));
@@ -181,7 +196,7 @@ static float noobs_intersection_terms(noobs_ctx *c, const orc_model *const *mode
         orc_se3_mul(T_mcs[d], c->T_cm[m], T_ds);
         orc_se3_invert(T_ds, T_sd);
         orc_ne_intersection(clouds[m], nClouds[m], T_ds, T_sd, models[m], c->T_fm[m], c->T_mf[m], models[d], c->T_fm[d], c->T_mf[d],
-                            0, dims, NULL, NULL, sys);
+                            redType, dims, A, map, sys);
         total += orc_unpack(eJ, JTJ, dims, sys, o->lambdaIntersection[m + d * n], dims);
     }
     return total;
@@ -204,7 +219,7 @@ float orc_get_error_noobs(const orc_model *const *models, float *const *T_mcs, f
         const int dims = c.dims[m];
         float *eJ = (float *)calloc((size_t)dims, sizeof(float));
         float *J = (float *)calloc((size_t)dims * dims, sizeof(float));
-        float *sys = (float *)malloc(sizeof(float) * (size_t)sys_len(dims));
+        float *sys = (float *)malloc(sizeof(float) * (size_t)sys_len(6 + models[m]->n_joints));
         /* getError adds every term's lambda-scaled e (optimizer.cpp:1047,1055) */
         error += noobs_intersection_terms(&c, models, T_mcs, m, o, clouds, nClouds, potentials, eJ, J, sys);
         free(eJ); free(J); free(sys);
@@ -239,7 +254,7 @@ float orc_optimize_poses_noobs(const orc_model *const *models, float *const *T_m
             const int dims = c.dims[m], off = c.offs[m];
             float *eJ = (float *)calloc((size_t)dims, sizeof(float));
             float *J = (float *)calloc((size_t)dims * dims, sizeof(float));
-            float *sys = (float *)malloc(sizeof(float) * (size_t)sys_len(dims));
+            float *sys = (float *)malloc(sizeof(float) * (size_t)sys_len(6 + models[m]->n_joints));
             eInt += noobs_intersection_terms(&c, models, T_mcs, m, o, clouds, nClouds, potentials, eJ, J, sys);
             /* symmetrise, += damping (zero), scatter the upper triangle (optimizer.cpp:881-905) */
             for (int i = 0; i < dims; ++i) for (int j = i; j < dims; ++j)
@@ -272,9 +287,14 @@ float orc_optimize_poses_noobs(const orc_model *const *models, float *const *T_m
             float dT[12];
             orc_se3_exp(x + c.offs[m], dT);
             orc_se3_mul(dT, T_mcs[m], T_mcs[m]);
-            for (int i = 0; i < models[m]->n_joints; ++i) {
-                const float v = joints[m][i] + x[c.offs[m] + 6 + i];
-                joints[m][i] = fminf(fmaxf(models[m]->joint_limits[2 * i], v), models[m]->joint_limits[2 * i + 1]);
+            if (!noobs_red_type(m)) {
+                for (int i = 0; i < models[m]->n_joints; ++i) {
+                    const float v = joints[m][i] + x[c.offs[m] + 6 + i];
+                    joints[m][i] = fminf(fmaxf(models[m]->joint_limits[2 * i], v), models[m]->joint_limits[2 * i + 1]);
+                }
+            } else {        /* reduced articulation, reduced limits (optimizer.cpp:948-950) */
+                for (int i = 0; i < g_noobsRed[m].redArt; ++i)
+                    joints[m][i] = fminf(fmaxf(g_noobsRed[m].mins[i], joints[m][i] + x[c.offs[m] + 6 + i]), g_noobsRed[m].maxs[i]);
             }
         }
         if (iterInfo) {

@@ -61,6 +61,8 @@ void orc_optimize_poses(const orc_model *const *models, float *const *T_mcs, flo
 
 /* ---- OptimizerNoObs (ContactGrasp refinement) ---- */
 #define ORC_MAX_MODELS 8
+/* pose reductions for the following NoObs calls ([nModels] or NULL); reduced models pass their reduced articulation as joints[m] */
+void orc_noobs_set_reductions(const orc_reduction *red);
 typedef struct {
     int32_t numIterations;
     int32_t nModels;

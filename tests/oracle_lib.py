@@ -330,16 +330,17 @@ def _noobs_args(oms, T_mcs, joints, clouds, potentials, priors):
     return models, T_keep, j_keep, T_ptrs, j_ptrs, c_ptrs, counts, p_ptrs, arr, (c_keep, p_keep)
 
 
-def optimize_poses_noobs(oms, T_mcs, joints, opts_struct, clouds, potentials, priors):
-    """orc_optimize_poses_noobs. opts_struct: NoObsOptions layout. Returns (T_mcs list, joints list, energy, iter_info, first)."""
+def optimize_poses_noobs(oms, T_mcs, joints, opts_struct, clouds, potentials, priors, dims=None):
+    """orc_optimize_poses_noobs. opts_struct: NoObsOptions layout. Returns (T_mcs list, joints list, energy, iter_info, first).
+    dims: per-model (reduced) dimensions when pose reductions are active (noobs_reductions)."""
     models, T_keep, j_keep, T_ptrs, j_ptrs, c_ptrs, counts, p_ptrs, arr, keep = _noobs_args(oms, T_mcs, joints, clouds, potentials, priors)
-    D = sum(o.dims for o in oms)
+    D = sum(o.dims for o in oms) if dims is None else sum(dims)
     info = np.zeros((max(opts_struct.numIterations, 1), 8), dtype=F)
     first = np.zeros(D * D + D, dtype=F)
     o = OrcNoObsOptions.from_buffer_copy(bytes(opts_struct))
     lib().orc_optimize_poses_noobs.restype = C.c_float
     e = lib().orc_optimize_poses_noobs(models, T_ptrs, j_ptrs, C.byref(o), c_ptrs, counts, p_ptrs, arr, len(priors), f(info), f(first))
-    return T_keep, [j_keep[m][:oms[m].n_joints] for m in range(len(oms))], float(e), info, first
+    return T_keep, [j_keep[m][:(oms[m].n_joints if dims is None else dims[m] - 6)] for m in range(len(oms))], float(e), info, first
 
 
 def get_error_noobs(oms, T_mcs, joints, opts_struct, clouds, potentials, priors):
@@ -352,6 +353,22 @@ def get_error_noobs(oms, T_mcs, joints, opts_struct, clouds, potentials, priors)
 # ---------------------------------------------------------------------------------------------- Optimizer::optimizePoses
 class OrcReduction(C.Structure):
     _fields_ = [("type", C.c_int32), ("redArt", C.c_int32), ("A", fp), ("b", fp), ("mapping", ip), ("mins", fp), ("maxs", fp)]
+
+
+class noobs_reductions:
+    """with noobs_reductions(tracker_no_obs): the oracle's NoObs calls use the tracker's pose reductions (the joints[m] arrays
+    then carry reduced articulations, and the system has the reduced dimensions)."""
+
+    def __init__(self, tracker):
+        self.arr, self.keep = tracker.reductions_struct(OrcReduction)
+
+    def __enter__(self):
+        lib().orc_noobs_set_reductions(self.arr)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_noobs_set_reductions(None)
+        return False
 
 
 class OrcMultiOptions(C.Structure):
