@@ -719,10 +719,21 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     const bool fork = useA && useB && o->numIterations > 0;
     hipStream_t stB = st, stA = fork ? ws->auxStream : st, stO = fork ? ws->auxStream2 : st;
     DARTK_HIP(hipMemsetAsync(ws->counters, 0, 2 * sizeof(int), st));      // before the fork; later iterations: zeroed by the solve kernel
+    // an error return after a fork must leave the caller's stream ordered after the side streams: they write the slab, index
+    // and system buffers of this workspace, which the next call on `st` reuses
+    struct JoinGuard {
+        Workspace *w; hipStream_t st, a, o; bool on;
+        ~JoinGuard() {
+            if (!on) return;
+            (void)hipEventRecord(w->evJoin, a); (void)hipEventRecord(w->evJoin2, o);
+            (void)hipStreamWaitEvent(st, w->evJoin, 0); (void)hipStreamWaitEvent(st, w->evJoin2, 0);
+        }
+    } joinGuard{ws, st, stA, stO, false};
     if (fork) {
         DARTK_HIP(hipEventRecord(ws->evFork, st));
         DARTK_HIP(hipStreamWaitEvent(stA, ws->evFork, 0));
         DARTK_HIP(hipStreamWaitEvent(stO, ws->evFork, 0));
+        joinGuard.on = true;
     }
     if (useB) {     // the obs SDF is first read by iteration 0's mod->obs kernel: built on a third stream beside the ray-cast
         {
@@ -807,6 +818,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         }
         DARTK_HIP(hipGetLastError());
     }
+    joinGuard.on = false;       // every iteration joined stA before its reduction; stO joined through evObs in iteration 0
     return DARTK_OK;
 }
 

@@ -51,8 +51,8 @@ class ImageDepthSource:
                 w, h = im.size
         self.width, self.height = int(w), int(h)
         pp = (float(principal_point[0]), float(principal_point[1]))
-        # a zero principal point means the image centre (depth_source.h constructor convention)
-        self.principal_point = pp if pp != (0.0, 0.0) else (self.width / 2.0, self.height / 2.0)
+        # only x is tested, and the centre is an INTEGER division (image_depth_source.h:227-231, :402-406)
+        self.principal_point = pp if pp[0] != 0.0 else (float(self.width // 2), float(self.height // 2))
         self._frame = 0
         return self._read()
 

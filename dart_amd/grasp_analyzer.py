@@ -18,7 +18,7 @@ import os
 
 import numpy as np
 
-from . import se3, sharding
+from . import configs, se3, sharding
 from .tracker_no_obs import ContactPrior, TrackerNoObs
 
 F = np.float32
@@ -232,12 +232,15 @@ class GraspAnalyser:
         self.hand_id, self.object_id = 0, 1
         # create_tracker (:392-436)
         self.tracker = TrackerNoObs(max_batch=max_batch)
-        self.tracker.addModel(hand, cloud_seed=11)
+        # the Barrett hand couples its 8 joints into 4 (LinearPoseReduction(8, 4), :393-420); every other hand is unreduced
+        self.reduction = configs.barrett_reduction(hand) if hand_name == "barrett" else None
+        self.tracker.addModel(hand, cloud_seed=11, reduction=self.reduction)
         if potential is not None:
             self.tracker.setIntersectionPotentialMatrix(self.hand_id, potential)
         self.hand, self.obj = hand, obj
-        self.n_dofs = hand.n_joints
-        self.graspit2dartdofs = list(range(self.n_dofs))       # identity mapping (:433-435)
+        # sized by getReducedArticulatedDimensions(), identity mapping (:427-435)
+        self.n_dofs = hand.n_joints if self.reduction is None else self.reduction.getReducedDimensions()
+        self.graspit2dartdofs = list(range(self.n_dofs))
         self.thumb_frame_id, self.thumb_contact_point = thumb if thumb is not None else (0, (0.0, 0.0, 0.0))
         self.grasps_T_cm = np.zeros((0, 12), dtype=F)
         self.grasps_dofs = np.zeros((0, self.n_dofs), dtype=F)
@@ -247,6 +250,14 @@ class GraspAnalyser:
         self.gt_frame_poses = None
         self.results = []
         self.optimized = None
+
+    def _full_joints(self, dofs):
+        """Pose::projectReducedToFull for the hand: the full joint vector of a (possibly reduced) articulation."""
+        if self.reduction is None:
+            return np.asarray(dofs, dtype=F)
+        full = np.zeros(self.hand.n_joints, dtype=F)
+        self.reduction.projectReducedToFull(np.asarray(dofs, dtype=F), full)
+        return full
 
     # ---- file names (:252-296, :814-820, :904-911)
     def _obj_base(self):
@@ -289,7 +300,7 @@ class GraspAnalyser:
             with open(self.gt_filename()) as f:
                 r = pose_from_string(f.readline(), self.n_dofs, self.graspit2dartdofs, read_gt=True)
             if r is not None:       # frame -> camera transforms of the ground-truth grasp (the object pose is identity)
-                T_mf = np.asarray(self.hand.forward_kinematics(r[1], "dh"), dtype=F).reshape(-1, 12)
+                T_mf = np.asarray(self.hand.forward_kinematics(self._full_joints(r[1]), "dh"), dtype=F).reshape(-1, 12)
                 self.gt_frame_poses = np.stack([se3.mul(r[0], T) for T in T_mf])
         cp, cn, ncp, ncn = read_contact_info(self.contact_filename(), self.scale)
         self.n_attract_points = min(len(cp), 500)
@@ -435,7 +446,7 @@ class GraspAnalyser:
             # the reference tests `type == 2 || type < 0` (:735): energy type 1 alone never yields the GT column there
             if (energy_type == 2 or energy_type < 0) and self.gt_frame_poses is not None:
                 T_mc_h, T_mc_o = poses[q, 0:12], poses[q, 12:24]
-                T_mf = np.asarray(self.hand.forward_kinematics(poses[q, 24:24 + nj], "dh"), dtype=F).reshape(-1, 12)
+                T_mf = np.asarray(self.hand.forward_kinematics(self._full_joints(poses[q, 24:24 + nj]), "dh"), dtype=F).reshape(-1, 12)
                 T_cm_h = se3.invert(T_mc_h)
                 frames = [se3.mul(T_mc_o, se3.mul(T_cm_h, Tf)) for Tf in T_mf[:len(self.gt_frame_poses)]]
                 r.append(compare_poses(frames, self.gt_frame_poses))

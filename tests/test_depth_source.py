@@ -35,6 +35,17 @@ def test_directory_and_format_initialisers(tmp_path):
     assert f.initialize_format(str(tmp_path / "depth_%04d.png"), (525.0, 525.0), (31.5, 23.5), 64, 48, first_depth_frame=6)
     assert f.getNumDepthFrames() == 2 and np.array_equal(f.getDepth(), frames[1]) and f.principal_point == (31.5, 23.5)
     assert not ImageDepthSource().initialize_directory(str(tmp_path / "missing"), (1, 1))
+    # the default principal point: integer division of an odd size, and only principalPoint.x is tested
+    # (image_depth_source.h:227-231)
+    odd = tmp_path / "odd"
+    odd.mkdir()
+    write_sequence(odd, n=1, w=63, h=47)
+    o = ImageDepthSource()
+    assert o.initialize_directory(str(odd), (525.0, 525.0)) and o.principal_point == (31.0, 23.0)
+    o2 = ImageDepthSource()
+    assert o2.initialize_directory(str(odd), (525.0, 525.0), (0.0, 20.0)) and o2.principal_point == (31.0, 23.0)
+    o3 = ImageDepthSource()
+    assert o3.initialize_directory(str(odd), (525.0, 525.0), (30.0, 0.0)) and o3.principal_point == (30.0, 0.0)
     g = ImageDepthSource()
     with pytest.raises(ValueError):
         g.initialize_directory(str(tmp_path), (525.0, 525.0), depth_width=32, depth_height=48)

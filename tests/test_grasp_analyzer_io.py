@@ -114,3 +114,28 @@ def test_umeyama_recovers_similarity():
     dst[:, 0] += 0.5                        # one outlier: RANSAC keeps the other six
     T2 = HF.estimate_srt(src, dst, n_iters=60, rng=np.random.default_rng(0))
     np.testing.assert_allclose(T2[:3, :3], 1.3 * A, atol=1e-6)
+
+
+def test_barrett_grasp_lines_carry_the_reduced_dofs(tmp_path):
+    """A reference-format *_grasps_barrett.csv / GT line holds 12 + 4 values: the Barrett pose has 4 reduced articulated dimensions
+    (LinearPoseReduction(8, 4), grasp_analyzer.cpp:393-420, :427-435), and pose_from_string fills exactly those."""
+    p = tmp_path / "obj_grasps_barrett.csv"
+    T = np.arange(24, dtype=np.float32).reshape(2, 12)
+    J = np.array([[0.1, 0.2, 0.3, 0.4], [0.5, 0.6, 0.7, 0.8]], dtype=np.float32)
+    GA.write_grasps_csv(str(p), T, J)
+    T2, J2 = GA.read_grasps_csv(str(p), 4, [0, 1, 2, 3])
+    np.testing.assert_allclose(J2, J, rtol=1e-6)
+    np.testing.assert_allclose(T2, T, rtol=1e-6)
+    # an 8-DOF reader finds too few values: the reference warns and pushes the unmodified template pose (:117-133, :277-281)
+    assert GA.pose_from_string(open(str(p)).readlines()[1], 8) is None
+    T3, J3 = GA.read_grasps_csv(str(p), 8)
+    assert T3.shape == (2, 12) and not J3.any()
+    # the reduction the analyser builds for the Barrett hand
+    from dart_amd import configs
+    class Hand:
+        joint_limits = [(0.0, 3.14), (0.0, 2.44), (0.0, 0.84), (0.0, 3.14), (0.0, 2.44), (0.0, 0.84), (0.0, 2.44), (0.0, 0.84)]
+        joint_names = ["j%d" % i for i in range(8)]
+    red = configs.barrett_reduction(Hand)
+    full = np.zeros(8, dtype=np.float32)
+    red.projectReducedToFull(np.array([1, 2, 3, 4], dtype=np.float32), full)
+    assert list(full) == [1, 2, 2, 1, 3, 3, 4, 4] and red.getReducedDimensions() == 4
