@@ -219,9 +219,12 @@ def _load(path):
         "dartk_noobs_set_priors": [vp, C.POINTER(ContactPriorC), C.c_int, vp],
         "dartk_noobs_set_point_priors": [vp, C.POINTER(PointPriorC), C.c_int, vp],
         "dartk_optimize_poses": [C.POINTER(MultiOptionsC), C.POINTER(MultiModelC), vp, vp, C.c_int, C.c_int, vp, vp, vp, vp],
+        "dartk_optimize_poses_priors": [C.POINTER(MultiOptionsC), C.POINTER(MultiModelC), vp, C.POINTER(ContactPriorC), C.c_int, vp, vp, C.c_int,
+                                        C.c_int, vp, vp, vp, vp],
         "dartk_optimize_poses_batch": [C.POINTER(MultiOptionsC), C.POINTER(MultiModelC), C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp],
         "dartk_noobs_optimize_poses": [vp, C.POINTER(NoObsOptions), C.c_int, vp, vp, vp, vp, vp, vp],
         "dartk_noobs_get_error": [vp, C.POINTER(NoObsOptions), C.c_int, vp, vp, vp, vp],
+        "dartk_noobs_contact_points": [vp, C.c_int, vp, vp],
         "dartk_lookup_counters": [C.POINTER(C.c_uint64), C.c_int],
         "dartk_profile_begin": [],
         "dartk_profile_end": [c_float_p, c_int_p],

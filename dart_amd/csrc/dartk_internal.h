@@ -362,6 +362,24 @@ __device__ __forceinline__ f3 sdf_gradient(const float *__restrict__ grids, cons
     r.z = 0.5f * (fpz - fmz);
     return r;
 }
+// projectToSdfSurface (sdf.cpp:6-23) in grid coordinates: steps of the interpolated distance along the normalised interpolated
+// gradient until |distance| < threshold (voxel units), the point leaves the gradient-interpolation bounds, or maxIters steps.
+// Not inlined into its callers: it runs for the rare contact priors that move their contact point.
+template <int CAT = CNT_OTHER>
+__device__ __noinline__ f3 project_to_sdf_surface(const float *__restrict__ grids, const SdfDev &s, f3 g, float threshold, int maxIters) {
+    for (int iter = 0; iter < maxIters; ++iter) {
+        if (!in_bounds_grad_interp(s, g)) return g;
+        const float dist = sdf_value<CAT>(grids, s, g);
+        if (fabsf(dist) < threshold) return g;
+        const f3 grad = sdf_gradient<CAT>(grids, s, g);
+        const float invLen = 1.0f / sqrtf(grad.x * grad.x + grad.y * grad.y + grad.z * grad.z);      // helper_math normalize on the host
+        g.x = g.x - dist * (grad.x * invLen);
+        g.y = g.y - dist * (grad.y * invLen);
+        g.z = g.z - dist * (grad.z * invLen);
+    }
+    return g;
+}
+
 
 // ---- articulated Jacobian (kernel_common.h:12-71) ---------------------------------------------------
 // Writes J[0..dims) (or the nJoints articulation entries when ARTIC_ONLY) with stride 1 into `J`.

@@ -42,6 +42,9 @@ struct MultiSolveArgs {
     size_t infoStride;
     // batch only: the caller's pose arrays, read before the first iteration / written after the last (iteration == -1 / -2)
     float *T_mcs;           // [frames][nModels][12]
+    // contact priors of the single-frame loop (optimizer.cpp:727-732, 757-759): device array, contact points updated in place
+    dartk_contact_prior *priors;
+    int nPriors;
 };
 
 // projection of the reduced articulation in ra[] (LDS) to the full joint vector (pose.cpp:66-73, 91-97) and forward
@@ -77,6 +80,102 @@ __device__ __forceinline__ void unpack_block(float *J, int ld, float *eJ, const 
     }
     for (int i = lane; i < d; i += 64) { float t = 0.0f; t += lam * sys[i]; eJ[shift + i] += t; }
     wave_sync_lds();
+}
+
+// ContactPrior::computeContribution (contact_prior.cpp:8-205) and updatePriorParams (:207-221) of one prior, by ONE lane: the
+// tracking loop carries a handful of priors (hand-object contacts), so they are evaluated in the solve kernel against the
+// poses of this iteration instead of in a term kernel of their own (ContactGrasp's thousands go through dartk_noobs).
+// Writes the prior's Jacobian row over the GLOBAL unknowns into L[0..D) and sc = {J^T e factor, weight, row is live};
+// moves the prior's contact point when it has update_contact_point.
+__device__ __noinline__ void multi_eval_contact_prior(const MultiSolveArgs &a, int frame, dartk_contact_prior *prp, float *L, float *sc) {
+    const dartk_contact_prior pr = *prp;
+    sc[0] = 0.0f; sc[1] = 0.0f; sc[2] = 0.0f;
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;          // solution of the prior's own three unknowns (update_contact_point)
+    for (int i = 0; i < a.D; ++i) L[i] = 0.0f;
+    ModelView ms = a.m[pr.srcModel].v, md = a.m[pr.dstModel].v;
+    select_frame(ms, frame); select_frame(md, frame);
+    do {
+        if (pr.weight == 0) break;
+        const int srcFrame = ms.sdfFrame[pr.srcSdf];
+        const f3 pm = se3_apply_w(ms.T_mf + 12 * srcFrame, pr.contactPoint[0], pr.contactPoint[1], pr.contactPoint[2], 1.0f);
+        const f3 cc = se3_apply_w(ms.T_cm, pm.x, pm.y, pm.z, 1.0f);
+        const f3 pdm = se3_apply_w(md.T_mc, cc.x, cc.y, cc.z, 1.0f);
+        // nearest destination SDF by raw voxel-unit value among the isInBoundsInterp grids (:41-54; the reference's loop bound
+        // `<= getNumSdfs()` reads one element past the end -- restated with `<`)
+        int dstSdf = -1;
+        float minV = 3.402823466e+38f;
+        for (int ds = 0; ds < md.nSdfs; ++ds) {
+            const SdfDev &s = md.sdfs[ds];
+            const f3 df = se3_apply_w(md.T_fm + 12 * md.sdfFrame[ds], pdm.x, pdm.y, pdm.z, 1.0f);
+            const f3 g = grid_coords(s, df);
+            if (!in_bounds_interp(s, g)) continue;
+            const float v = sdf_value<CNT_PRIOR>(md.grids, s, g);
+            if (v < minV) { minV = v; dstSdf = ds; }
+        }
+        if (dstSdf < 0) break;
+        const int dstFrame = md.sdfFrame[dstSdf];
+        const SdfDev &s = md.sdfs[dstSdf];
+        const f3 cg = grid_coords(s, se3_apply_w(md.T_fm + 12 * dstFrame, pdm.x, pdm.y, pdm.z, 1.0f));
+        if (!in_bounds_grad_interp(s, cg)) break;
+        float err = sdf_value<CNT_PRIOR>(md.grids, s, cg) * s.res;
+        if (fabsf(err) > pr.contactThreshold) break;
+        if ((double)fabsf(err) < 1e-4) break;                           // :70-73
+        const f3 g_df = sdf_gradient<CNT_PRIOR>(md.grids, s, cg);
+        const f3 gdm = se3_rotate(md.T_mf + 12 * dstFrame, g_df);
+        const f3 g_c = se3_rotate(md.T_cm, gdm);
+        const f3 gsm = se3_rotate(ms.T_mc, g_c);
+        const f3 g_sf = se3_rotate(ms.T_fm + 12 * srcFrame, gsm);
+        if (pr.invert && err > 0) {                                     // repulsive cylinder test, :84-89
+            const float invLen = 1.0f / sqrtf(dot(g_sf, g_sf));
+            f3 n; n.x = g_sf.x * invLen; n.y = g_sf.y * invLen; n.z = g_sf.z * invLen;
+            f3 nsf; nsf.x = pr.normal[0]; nsf.y = pr.normal[1]; nsf.z = pr.normal[2];
+            const float cosT = dot(nsf, n);
+            const float sinT = sqrtf(1.f - cosT * cosT);
+            if (fabsf(err * sinT) > 0.01f) break;
+        }
+        if (pr.invert) err *= -1.f;
+        if (!(pr.updateContact || pr.updateSrc || pr.updateDst)) break;
+        // the priors index the model Jacobian by the pose's REDUCED dimensions (:31-32,110-126): the first dims columns of the
+        // full Jacobian, as the reference computes it
+        const MultiSolveModel &sm = a.m[pr.srcModel], &dm = a.m[pr.dstModel];
+        if (pr.updateSrc)
+            error_jacobian<false>(L + sm.off, pm, 1.0f, ms.depMask[srcFrame], gsm, sm.dims - 6, ms.jointType, ms.jointAxis, ms.T_fm, ms.T_mf);
+        if (pr.updateDst) {
+            float *rd = L + dm.off;
+            error_jacobian<false>(rd, pdm, 1.0f, md.depMask[dstFrame], gdm, dm.dims - 6, md.jointType, md.jointAxis, md.T_fm, md.T_mf);
+            for (int i = 0; i < dm.dims; ++i) rd[i] = -rd[i];
+        }
+        const float we = pr.weight * err;
+        float fold = we;
+        if (pr.updateContact) {
+            // the prior's three unknowns lie behind the model blocks; the back substitution (:732) takes the last columns first and
+            // these touch no other prior's, so their solution needs this prior's block U = (w g) g^T, b = (w err) g only
+            // (:104-108,128-129,151-157), and each solved t_k takes t_k (w J_i) g_k out of the model rows (:173-186)
+            const float wg0 = pr.weight * g_sf.x, wg1 = pr.weight * g_sf.y, wg2 = pr.weight * g_sf.z;
+            float b0 = we * g_sf.x, b1 = we * g_sf.y, b2 = we * g_sf.z;
+            if (b2 != 0.0f) {
+                t2 = b2 / (wg2 * g_sf.z);
+                const float u02 = wg0 * g_sf.z, u12 = wg1 * g_sf.z;
+                if (u02 != 0.0f) b0 -= t2 * u02;
+                if (u12 != 0.0f) b1 -= t2 * u12;
+            }
+            if (b1 != 0.0f) {
+                t1 = b1 / (wg1 * g_sf.y);
+                const float u01 = wg0 * g_sf.y;
+                if (u01 != 0.0f) b0 -= t1 * u01;
+            }
+            if (b0 != 0.0f) t0 = b0 / (wg0 * g_sf.x);
+            fold = ((we - t2 * wg2) - t1 * wg1) - t0 * wg0;
+        }
+        sc[0] = fold; sc[1] = pr.weight; sc[2] = (pr.updateSrc || pr.updateDst) ? 1.0f : 0.0f;
+    } while (0);
+    if (pr.updateContact) {     // updatePriorParams with -solution, then back onto the source SDF's surface (:207-221)
+        const SdfDev &s = ms.sdfs[pr.srcSdf];
+        f3 cp;
+        cp.x = pr.contactPoint[0] + (-t0); cp.y = pr.contactPoint[1] + (-t1); cp.z = pr.contactPoint[2] + (-t2);
+        const f3 est = project_to_sdf_surface<CNT_PRIOR>(ms.grids, s, grid_coords(s, cp), 1e-9f, 100);
+        prp->contactPoint[0] = s.res * est.x + s.ox; prp->contactPoint[1] = s.res * est.y + s.oy; prp->contactPoint[2] = s.res * est.z + s.oz;
+    }
 }
 
 __global__ void __launch_bounds__(64)
@@ -152,6 +251,24 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration) {
         for (int i = lane; i < dims; i += 64) bv[off + i] = eJ[i];
         wave_sync_lds();
     }
+    // priors[p]->computeContribution into the assembled system, in list order (:727-730): J^T e += (w err) J, upper J^T J +=
+    // (w J_r) J_c over the source block, the destination block and their cross block (contact_prior.cpp:128-157,187-204)
+    for (int p = 0; p < a.nPriors; ++p) {
+        float *L = J, *sc = eJ;
+        if (lane == 0) multi_eval_contact_prior(a, frame, a.priors + p, L, sc);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (sc[2] != 0.0f) {
+            const float fold = sc[0], w = sc[1];
+            for (int idx = lane; idx < D * D; idx += 64) {
+                const int r = idx / D, c = idx - r * D;
+                if (c < r) continue;
+                const float val = (w * L[r]) * L[c];
+                if (val != 0.0f) U[r * ldU + c] += val;
+            }
+            for (int i = lane; i < D; i += 64) bv[i] += fold * L[i];
+        }
+        wave_sync_lds();
+    }
     if (a.firstSystem && iteration == 0 && frame == 0) {
         for (int idx = lane; idx < D * D; idx += 64) a.firstSystem[idx] = U[(idx / D) * ldU + (idx % D)];
         for (int i = lane; i < D; i += 64) a.firstSystem[D * D + i] = bv[i];
@@ -223,7 +340,8 @@ static int multi_scratch(size_t bytes, void **out) {
 // wave per frame); the frames share the models' SDFs and tables and differ in observation maps, poses and observation SDFs.
 static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_model *mm, int nFrames, const float *d_vert,
                                const float *d_norm, int width, int height, float *d_prediction, float *d_T_mcs, float *d_redArtBatch,
-                               float *d_iterInfo, float *d_firstSystem, hipStream_t st) {
+                               float *d_iterInfo, float *d_firstSystem, hipStream_t st, dartk_contact_prior *d_priors = nullptr,
+                               int nPriors = 0) {
     const int n = o->nModels;
     const bool batch = d_T_mcs != nullptr;
     const bool useA = o->lambdaObsToMod > 0, useB = o->lambdaModToObs > 0;
@@ -358,6 +476,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     h.nModels = n; h.D = D; h.numIterations = o->numIterations;
     h.lambdaA = o->lambdaObsToMod; h.lambdaB = o->lambdaModToObs;
     h.iterInfo = d_iterInfo; h.firstSystem = d_firstSystem;
+    h.priors = d_priors; h.nPriors = nPriors;
     h.fb = fb; h.redStride = batch ? redTotal : 0; h.infoStride = batch ? (size_t)o->numIterations * n * 8 : 0; h.T_mcs = d_T_mcs;
     DARTK_HIP(hipMemcpyAsync(d_args, &h, sizeof(h), hipMemcpyHostToDevice, st));
     if (!tables.empty()) DARTK_HIP(hipMemcpyAsync(fl, tables.data(), sizeof(float) * tables.size(), hipMemcpyHostToDevice, st));
@@ -520,6 +639,35 @@ int dartk_optimize_poses(const dartk_multi_options *o, const dartk_multi_model *
                       o->predWidth, o->predHeight, width, height);
     }
     return optimize_poses_impl(o, mm, 1, d_vert, d_norm, width, height, d_prediction, nullptr, nullptr, d_iterInfo, d_firstSystem, as_stream(stream));
+}
+
+int dartk_optimize_poses_priors(const dartk_multi_options *o, const dartk_multi_model *mm, dartk_contact_prior *d_priors,
+                                const dartk_contact_prior *h_priors, int nPriors, const float *d_vert, const float *d_norm, int width,
+                                int height, float *d_prediction, float *d_iterInfo, float *d_firstSystem, void *stream) {
+    DARTK_REQUIRE(o && mm, "dartk_optimize_poses_priors: null argument");
+    DARTK_REQUIRE(nPriors >= 0 && (nPriors == 0 || (d_priors && h_priors)), "bad prior list");
+    const int n = o->nModels;
+    DARTK_REQUIRE(n >= 1 && n <= DARTK_MAX_MODELS, "nModels %d out of range [1,%d]", n, DARTK_MAX_MODELS);
+    for (int p = 0; p < nPriors; ++p) {
+        const dartk_contact_prior &q = h_priors[p];
+        DARTK_REQUIRE(q.srcModel >= 0 && q.srcModel < n && q.dstModel >= 0 && q.dstModel < n && mm[q.srcModel].model && mm[q.dstModel].model,
+                      "contact prior %d: model index out of range", p);
+        DARTK_REQUIRE(q.srcSdf >= 0 && q.srcSdf < reinterpret_cast<Model *>(mm[q.srcModel].model)->v.nSdfs, "contact prior %d: SDF index out of range", p);
+        DARTK_REQUIRE(q.srcModel != q.dstModel, "contact prior %d: source and destination model must differ", p);
+    }
+    hipStream_t st = as_stream(stream);
+    if (nPriors) DARTK_HIP(hipMemcpyAsync(d_priors, h_priors, sizeof(dartk_contact_prior) * (size_t)nPriors, hipMemcpyHostToDevice, st));
+    DARTK_REQUIRE(d_vert && d_norm, "dartk_optimize_poses_priors: null argument");
+    DARTK_REQUIRE(width > 0 && height > 0 && (long long)width * height < (1ll << 31), "bad map size %dx%d", width, height);
+    DARTK_REQUIRE(o->numIterations >= 0, "negative iteration count");
+    if (o->lambdaModToObs > 0) {
+        DARTK_REQUIRE(d_prediction && o->predWidth > 0 && o->predHeight > 0, "mod->obs term needs a prediction buffer");
+        DARTK_REQUIRE((o->predWidth - 1) * width / o->predWidth + 1 < width && (o->predHeight - 1) * height / o->predHeight + 1 < height,
+                      "cullUnobservable reads a 2x2 observation neighbourhood: the prediction (%dx%d) must be smaller than the observation map (%dx%d)",
+                      o->predWidth, o->predHeight, width, height);
+    }
+    return optimize_poses_impl(o, mm, 1, d_vert, d_norm, width, height, d_prediction, nullptr, nullptr, d_iterInfo, d_firstSystem, st, d_priors,
+                               nPriors);
 }
 
 int dartk_optimize_poses_batch(const dartk_multi_options *o, const dartk_multi_model *mm, int nFrames, const float *d_vert,

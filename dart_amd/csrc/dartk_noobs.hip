@@ -26,8 +26,12 @@ namespace dartk {
 #ifndef NOOBS_ROWS
 #define NOOBS_ROWS 32        // rows of parked active points per workgroup (<= NE_BLOCK)
 #endif
-enum { TERM_SELF = 0, TERM_INTER = 1, TERM_PRIORS = 2, TERM_POINTS = 3 };
-__host__ __device__ constexpr bool term_weighted(int type) { return type == TERM_PRIORS || type == TERM_POINTS; }
+// TERM_PRIORS_UPD: the contact-prior term when some prior has update_contact_point (own instantiation, so that the contact
+// point solve and the surface projection cost the ContactGrasp configuration, whose contact points are frozen, nothing)
+enum { TERM_SELF = 0, TERM_INTER = 1, TERM_PRIORS = 2, TERM_POINTS = 3, TERM_PRIORS_UPD = 4 };
+__host__ __device__ constexpr bool term_contact(int type) { return type == TERM_PRIORS || type == TERM_PRIORS_UPD; }
+__host__ __device__ constexpr bool term_weighted(int type) { return term_contact(type) || type == TERM_POINTS; }
+enum { NOOBS_USE_CONTACTS = 1, NOOBS_MOVE_CONTACTS = 2 };      // flags of a terms launch
 static constexpr int NOOBS_MAX_TERMS = DARTK_MAX_MODELS * DARTK_MAX_MODELS + 2;
 
 struct NoObsTerm {
@@ -61,13 +65,16 @@ struct NoObsProblem {            // device-visible description shared by both ke
     ModelView model[DARTK_MAX_MODELS];   // static tables only; pose pointers are rebased per candidate
     NoObsTerm term[NOOBS_MAX_TERMS];
     const dartk_contact_prior *priors;
+    // update_contact_point: every candidate's own contact points [candidate][prior][3] (the reference mutates the prior
+    // objects, contact_prior.cpp:212-219; candidates of a batch are independent, so each carries its copy)
+    float *contactPts;
     const dartk_point_prior *pointPriors;     // Point3D3DPrior / Point2D3DPrior list, three rows each (TERM_POINTS)
     int nPointPriors;
 };
 
 #ifdef DARTK_STAMPS
 // diagnostic build only: cycles of thread 0 of every workgroup per phase, summed per term type
-__device__ unsigned long long g_noobsStamps[3][8];
+__device__ unsigned long long g_noobsStamps[5][8];
 #define NOOBS_STAMP(ph) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); atomicAdd(&g_noobsStamps[TYPE][ph], now_ - stampT); stampT = now_; } } while (0)
 #else
 #define NOOBS_STAMP(ph) do { } while (0)
@@ -156,7 +163,8 @@ noobs_load_poses_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ 
 #endif
 template <int TPT, int TYPE>
 __global__ void __launch_bounds__(NE_BLOCK) __attribute__((amdgpu_waves_per_eu(term_weighted(TYPE) ? NOOBS_WAVES_PRIORS : NOOBS_WAVES_INTER)))
-noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses, float *__restrict__ slabs, int termIdx, int potLdsInts) {
+noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses, float *__restrict__ slabs, int termIdx, int potLdsInts,
+                   int flags) {
     extern __shared__ float lds[];
 #ifdef DARTK_STAMPS
     unsigned long long stampT = clock64();
@@ -246,6 +254,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     acc.init(d);
     NOOBS_STAMP(1);
     constexpr bool WEIGHTED = term_weighted(TYPE);
+    constexpr bool UPD = TYPE == TERM_PRIORS_UPD;
     const int lOff = tile_l_off(d, WEIGHTED);
     double errInactive = 0.0;       // contact priors: _error of priors that contribute no row
     // rows of the parked points [0, n): Jacobians by the first n threads, then every thread adds its packed entries
@@ -283,7 +292,9 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                     for (int i = 0; i < nd; ++i) rd[i] = -rd[i];
                 }
                 L[d] = 1.0f;
-                row[0] = weight * residual;         // J^T e += (w*err) * J   (:128)
+                // J^T e += (w*err) * J (:128); a prior that also solves for its contact point parks that factor with the
+                // contact point's share of the back substitution already taken out (see the evaluation below)
+                row[0] = (UPD && ((packed >> 26) & 1)) ? residual : weight * residual;
                 row[1] = E;
                 for (int i = 0; i < d; ++i) row[2 + i] = weight * L[i];      // (w*J) J^T   (:129)
             } else {
@@ -324,6 +335,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         int srcFrame = 0, dstFrame = 0, pSrc = 0, pDst = 0;
         float residual = 0.0f, weight = 0.0f, E = 0.0f;
         bool upSrc = true, upDst = false;
+        bool folded = false;                   // the parked residual already is the row's J^T e factor (TERM_PRIORS_UPD)
         if (index < T.nPoints) {
             if constexpr (TYPE == TERM_SELF) {
                 const float4 v = T.cloud[index];
@@ -394,7 +406,15 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                 }
             } else {
                 // ContactPrior::computeContribution, contact_prior.cpp:17-95
-                const dartk_contact_prior pr = P->priors[index];
+                dartk_contact_prior pr = P->priors[index];
+                float *cpSlot = nullptr;
+                float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;      // UPD: the solution of the prior's own three unknowns
+                if constexpr (UPD) {
+                    if (pr.updateContact && (flags & NOOBS_USE_CONTACTS)) {
+                        cpSlot = P->contactPts + ((size_t)c * P->nPriors + index) * 3;
+                        pr.contactPoint[0] = cpSlot[0]; pr.contactPoint[1] = cpSlot[1]; pr.contactPoint[2] = cpSlot[2];
+                    }
+                }
                 const int sign = pr.invert ? -1 : 1;
                 E = sign * pr.weight * pr.contactThreshold;
                 if (pr.weight != 0) {
@@ -457,6 +477,36 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                                         residual = err; weight = pr.weight;
                                         upSrc = pr.updateSrc != 0; upDst = pr.updateDst != 0;
                                         active = upSrc || upDst;
+                                        if constexpr (UPD) {
+                                            if (pr.updateContact) {
+                                                // The prior's three contact-point unknowns sit behind the model blocks (optimizer.cpp:
+                                                // 829-832) and the reference back-substitutes the upper triangle last column first
+                                                // (:931): these three columns come before every model column and touch no other
+                                                // prior's, so their solution needs only this prior's block U = (w g) g^T, b = (w err) g
+                                                // (contact_prior.cpp:104-108,128-129,151-157; the regularisation of :162-170 is applied
+                                                // to a copy that is never read again). Each solved unknown t_k then takes
+                                                // t_k * U[model row][k] = t_k * (w J_i) g_k out of the model rows' right-hand side
+                                                // (:173-186): the factor below. Eigen skips a column whose right-hand side is exactly 0.
+                                                const f3 g = se3_rotate(sfm + 12 * srcFrame, gs);
+                                                const float we = pr.weight * err;
+                                                const float wg0 = pr.weight * g.x, wg1 = pr.weight * g.y, wg2 = pr.weight * g.z;
+                                                float b0 = we * g.x, b1 = we * g.y, b2 = we * g.z;
+                                                if (b2 != 0.0f) {
+                                                    t2 = b2 / (wg2 * g.z);
+                                                    const float u02 = wg0 * g.z, u12 = wg1 * g.z;
+                                                    if (u02 != 0.0f) b0 -= t2 * u02;
+                                                    if (u12 != 0.0f) b1 -= t2 * u12;
+                                                }
+                                                if (b1 != 0.0f) {
+                                                    t1 = b1 / (wg1 * g.y);
+                                                    const float u01 = wg0 * g.y;
+                                                    if (u01 != 0.0f) b0 -= t1 * u01;
+                                                }
+                                                if (b0 != 0.0f) t0 = b0 / (wg0 * g.x);
+                                                residual = ((we - t2 * wg2) - t1 * wg1) - t0 * wg0;
+                                                folded = true;
+                                            }
+                                        }
                                     }
                                 }
                             }
@@ -464,6 +514,19 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                     }
                 }
                 if (!active) errInactive += (double)E;
+                if constexpr (UPD) {
+                    // ContactPrior::updatePriorParams (contact_prior.cpp:207-221) with this prior's part of paramUpdate = -solution
+                    // (optimizer.cpp:931,956-958): every prior that updates its contact point, active or not, steps and is
+                    // projected back onto its own SDF's surface
+                    if (cpSlot && (flags & NOOBS_MOVE_CONTACTS)) {
+                        const ModelView &mo = P->model[pr.srcModel];
+                        const SdfDev &s = sSdf(pr.srcModel)[pr.srcSdf];
+                        f3 cp;
+                        cp.x = pr.contactPoint[0] + (-t0); cp.y = pr.contactPoint[1] + (-t1); cp.z = pr.contactPoint[2] + (-t2);
+                        const f3 est = project_to_sdf_surface<CNT_PRIOR>(mo.grids, s, grid_coords(s, cp), 1e-9f, 100);
+                        cpSlot[0] = s.res * est.x + s.ox; cpSlot[1] = s.res * est.y + s.oy; cpSlot[2] = s.res * est.z + s.oz;   // getWorldCoords
+                    }
+                }
             }
         }
         // Active points are rare and scattered over the lanes: park their state (compacted, in evaluation order) in the
@@ -479,7 +542,8 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                 float *e = rows + (pending + slot - base) * ld;
                 e[0] = pm.x; e[1] = pm.y; e[2] = pm.z; e[3] = gs.x; e[4] = gs.y; e[5] = gs.z; e[6] = residual;
                 if constexpr (WEIGHTED) {
-                    e[7] = __int_as_float(srcFrame | (dstFrame << 8) | (pSrc << 16) | (pDst << 20) | ((int)upSrc << 24) | ((int)upDst << 25));
+                    e[7] = __int_as_float(srcFrame | (dstFrame << 8) | (pSrc << 16) | (pDst << 20) | ((int)upSrc << 24) | ((int)upDst << 25) |
+                                          ((int)folded << 26));
                     e[8] = pdm.x; e[9] = pdm.y; e[10] = pdm.z; e[11] = gdm.x; e[12] = gdm.y; e[13] = gdm.z; e[14] = weight; e[15] = E;
                 } else {
                     e[7] = __int_as_float(srcFrame);
@@ -493,7 +557,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         NOOBS_STAMP(3);
     }
     flush(pending);
-    if constexpr (TYPE == TERM_PRIORS) {    // add the _error of the row-less priors to the e slot, fixed order
+    if constexpr (term_contact(TYPE)) {    // add the _error of the row-less priors to the e slot, fixed order
         double v = errInactive;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -559,7 +623,7 @@ noobs_solve_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                 if (v != 0) U[i * ld + j] += v;
             }
             for (int i = lane; i < D; i += 64) b[i] += sys[i];
-            if (T.type == TERM_PRIORS) ePri = sys[T.S - 1];
+            if (term_contact(T.type)) ePri = sys[T.S - 1];
         } else {
             const int m = T.src;
             const float lam = a.lambda[T.src + T.dst * nModels];
@@ -652,6 +716,15 @@ noobs_solve_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     }
 }
 
+// every candidate starts from the priors' own contact points
+__global__ void noobs_init_contacts_kernel(const NoObsProblem *__restrict__ P, int batch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * P->nPriors) return;
+    const dartk_contact_prior &pr = P->priors[i % P->nPriors];
+    float *cp = P->contactPts + (size_t)i * 3;
+    cp[0] = pr.contactPoint[0]; cp[1] = pr.contactPoint[1]; cp[2] = pr.contactPoint[2];
+}
+
 // export poses of the batch
 __global__ void noobs_store_poses_kernel(const NoObsProblem *__restrict__ P, const float *__restrict__ poses, float *__restrict__ T_mcs,
                                          float *__restrict__ joints) {
@@ -676,6 +749,9 @@ struct NoObs {
     int maxBatch;
     int ldsModels, slabFloats;     // LDS floats of the staged model tables; slab floats per candidate of the fixed terms
     float *poses, *slabs;
+    float *contactPts;         // [maxBatch][nPriors][3] when a prior updates its contact point, else null
+    bool anyUpdate;
+    int termFlags;             // NOOBS_* flags of the next terms launch
     int SMax, maxFrames, potLdsInts;
     size_t ldsTerm[NOOBS_MAX_TERMS], ldsSolve;
     bool lambdaActive[DARTK_MAX_MODELS * DARTK_MAX_MODELS];
@@ -694,7 +770,7 @@ static int noobs_launch_term(NoObs *t, int term, int batch, hipStream_t st) {
     if (lds > 64 * 1024) DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     static const bool dbgOcc = getenv("DARTK_DEBUG_OCCUPANCY") != nullptr;      // diagnostic: resident workgroups per CU
     if (dbgOcc) {
-        static bool once[4][3];
+        static bool once[5][3];
         if (!once[TYPE][TPT]) {
             once[TYPE][TPT] = true;
             int nb = 0;
@@ -702,7 +778,8 @@ static int noobs_launch_term(NoObs *t, int term, int batch, hipStream_t st) {
             fprintf(stderr, "[dartk] noobs_terms_kernel<%d,%d>: %zu B dynamic LDS, %d workgroups of %d threads per CU\n", TPT, TYPE, lds, nb, NE_BLOCK);
         }
     }
-    hipLaunchKernelGGL(kfn, dim3(t->h.term[term].nBlocks, batch), dim3(NE_BLOCK), lds, st, t->d, t->poses, t->slabs, term, t->potLdsInts);
+    hipLaunchKernelGGL(kfn, dim3(t->h.term[term].nBlocks, batch), dim3(NE_BLOCK), lds, st, t->d, t->poses, t->slabs, term, t->potLdsInts,
+                       t->termFlags);
     return DARTK_OK;
 }
 
@@ -724,6 +801,7 @@ static int noobs_launch_terms(NoObs *t, int batch, hipStream_t st) {
         case TERM_SELF: rc = noobs_launch_term_ppt<TERM_SELF>(t, i, batch, st); break;
         case TERM_INTER: rc = noobs_launch_term_ppt<TERM_INTER>(t, i, batch, st); break;
         case TERM_POINTS: rc = noobs_launch_term_ppt<TERM_POINTS>(t, i, batch, st); break;
+        case TERM_PRIORS_UPD: rc = noobs_launch_term_ppt<TERM_PRIORS_UPD>(t, i, batch, st); break;
         default: rc = noobs_launch_term_ppt<TERM_PRIORS>(t, i, batch, st); break;
         }
         if (rc) return rc;
@@ -750,6 +828,7 @@ int dartk_noobs_destroy(dartk_noobs_t h) {
     if (t->d_priors) (void)hipFree(t->d_priors);
     if (t->d_pointPriors) (void)hipFree(t->d_pointPriors);
     if (t->d_redTables) (void)hipFree(t->d_redTables);
+    if (t->contactPts) (void)hipFree(t->contactPts);
     if (t->poses) (void)hipFree(t->poses);
     if (t->slabs) (void)hipFree(t->slabs);
     delete t;
@@ -835,12 +914,7 @@ int dartk_noobs_create_reduced(int nModels, const dartk_model_t *models, const d
             delete t; set_error("contact prior %d: model / SDF index out of range", p); return DARTK_ERR_INVALID;
         }
         if (q.srcModel == q.dstModel) { delete t; set_error("contact prior %d: source and destination model must differ", p); return DARTK_ERR_UNSUPPORTED; }
-        if (q.updateContact) {
-            delete t;
-            set_error("contact prior %d: update_contact_point is not supported on the device path (ContactGrasp freezes the contact points, "
-                      "grasp_analyzer.cpp:359,374,383)", p);
-            return DARTK_ERR_UNSUPPORTED;
-        }
+        if (q.updateContact) t->anyUpdate = true;
     }
     // term table in the reference's evaluation order: per model self-intersection, then the other models; priors last
     int nTerms = 0, slabOff = 0, SMax = 0;
@@ -873,7 +947,7 @@ int dartk_noobs_create_reduced(int nModels, const dartk_model_t *models, const d
             add(TERM_INTER, m, d, nCloudPoints[m], P.dims[m], d_clouds[m], nullptr);
         }
     }
-    if (nPriors > 0) add(TERM_PRIORS, 0, 0, nPriors, D, nullptr, nullptr);
+    if (nPriors > 0) add(t->anyUpdate ? TERM_PRIORS_UPD : TERM_PRIORS, 0, 0, nPriors, D, nullptr, nullptr);
     for (int i = 0; i < nModels * nModels; ++i) t->lambdaActive[i] = h_lambdaIntersection[i] > 0;
     P.nTerms = nTerms; P.slabStride = slabOff > 0 ? slabOff : 1;
     t->ldsModels = ldsModels; t->slabFloats = slabOff;
@@ -890,6 +964,8 @@ int dartk_noobs_create_reduced(int nModels, const dartk_model_t *models, const d
         if (e == hipSuccess) e = hipMemcpy(t->d_priors, h_priors, sizeof(dartk_contact_prior) * (size_t)nPriors, hipMemcpyHostToDevice);
     }
     P.priors = t->d_priors;
+    if (e == hipSuccess && t->anyUpdate) e = hipMalloc((void **)&t->contactPts, sizeof(float) * 3 * (size_t)nPriors * maxBatch);
+    P.contactPts = t->contactPts;
     if (e == hipSuccess) e = hipMalloc((void **)&t->d, sizeof(NoObsProblem));
     if (e == hipSuccess) e = hipMemcpy(t->d, &P, sizeof(NoObsProblem), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&t->poses, sizeof(float) * (size_t)P.poseStride * maxBatch);
@@ -908,7 +984,8 @@ int dartk_noobs_set_priors(dartk_noobs_t h, const dartk_contact_prior *h_priors,
     DARTK_REQUIRE(t && (h_priors || nPriors == 0), "dartk_noobs_set_priors: null argument");
     DARTK_REQUIRE(nPriors == t->nPriors, "the number of priors (%d) is fixed at creation (%d)", nPriors, t->nPriors);
     for (int p = 0; p < nPriors; ++p)
-        DARTK_REQUIRE(!h_priors[p].updateContact, "contact prior %d: update_contact_point is not supported on the device path", p);
+        DARTK_REQUIRE(!h_priors[p].updateContact || t->anyUpdate,
+                      "contact prior %d: update_contact_point switched on after dartk_noobs_create (the term's form is fixed at creation)", p);
     if (nPriors) {
         DARTK_HIP(hipMemcpyAsync(t->d_priors, h_priors, sizeof(dartk_contact_prior) * (size_t)nPriors, hipMemcpyHostToDevice, as_stream(stream)));
         DARTK_HIP(hipStreamSynchronize(as_stream(stream)));
@@ -1004,23 +1081,37 @@ int dartk_noobs_optimize_poses(dartk_noobs_t h, const dartk_noobs_options *o, in
     if (t->ldsSolve > 64 * 1024)
         DARTK_HIP(hipFuncSetAttribute((const void *)noobs_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->ldsSolve));
     hipLaunchKernelGGL(noobs_load_poses_kernel, dim3(t->h.nModels, batch), dim3(64), 0, st, t->d, t->poses, d_T_mcs, d_joints);
+    if (t->anyUpdate)
+        hipLaunchKernelGGL(noobs_init_contacts_kernel, dim3((batch * t->nPriors + 255) / 256), dim3(256), 0, st, t->d, batch);
     NoObsSolveArgs a;
     noobs_fill_args(t, o, a);
     a.energy = d_energy; a.iterInfo = d_iterInfo; a.firstSystem = d_firstSystem;
     for (int it = 0; it < o->numIterations; ++it) {
+        t->termFlags = NOOBS_USE_CONTACTS | NOOBS_MOVE_CONTACTS;
         rc = noobs_launch_terms(t, batch, st);
         if (rc) return rc;
         a.iteration = it; a.energyOnly = 0;
         ProfScope ps(DARTK_PROF_NOOBS_SOLVE, st);
         hipLaunchKernelGGL(noobs_solve_kernel, dim3(batch), dim3(64), t->ldsSolve, st, t->d, t->poses, t->slabs, a);
     }
-    // getError at the final poses (optimizer.cpp:980-982)
+    // getError at the final poses and contact points (optimizer.cpp:980-982)
+    t->termFlags = NOOBS_USE_CONTACTS;
     rc = noobs_launch_terms(t, batch, st);
     if (rc) return rc;
     a.energyOnly = 1;
     hipLaunchKernelGGL(noobs_solve_kernel, dim3(batch), dim3(64), t->ldsSolve, st, t->d, t->poses, t->slabs, a);
     hipLaunchKernelGGL(noobs_store_poses_kernel, dim3(t->h.nModels, batch), dim3(64), 0, st, t->d, t->poses, d_T_mcs, d_joints);
     DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
+int dartk_noobs_contact_points(dartk_noobs_t h, int batch, float *d_contactPoints, void *stream) {
+    NoObs *t = reinterpret_cast<NoObs *>(h);
+    DARTK_REQUIRE(t && d_contactPoints, "dartk_noobs_contact_points: null argument");
+    DARTK_REQUIRE(batch >= 1 && batch <= t->maxBatch, "batch %d out of range [1,%d]", batch, t->maxBatch);
+    DARTK_REQUIRE(t->anyUpdate, "no contact prior of this tracker updates its contact point");
+    DARTK_HIP(hipMemcpyAsync(d_contactPoints, t->contactPts, sizeof(float) * 3 * (size_t)t->nPriors * batch, hipMemcpyDeviceToDevice,
+                             as_stream(stream)));
     return DARTK_OK;
 }
 
@@ -1035,6 +1126,7 @@ int dartk_noobs_get_error(dartk_noobs_t h, const dartk_noobs_options *o, int bat
     if (t->ldsSolve > 64 * 1024)
         DARTK_HIP(hipFuncSetAttribute((const void *)noobs_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->ldsSolve));
     hipLaunchKernelGGL(noobs_load_poses_kernel, dim3(t->h.nModels, batch), dim3(64), 0, st, t->d, t->poses, d_T_mcs, d_joints);
+    t->termFlags = 0;           // the priors' own contact points
     rc = noobs_launch_terms(t, batch, st);
     if (rc) return rc;
     NoObsSolveArgs a;

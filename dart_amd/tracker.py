@@ -64,6 +64,13 @@ class Tracker:
         self.iteration_summaries = None
         self.first_system = None
 
+    def addPrior(self, prior):
+        """Tracker::addPrior (tracker.h): a tracker_no_obs.ContactPrior evaluated in every iteration of optimizePoses."""
+        self.priors.append(prior)
+
+    def clearPriors(self):
+        self.priors = []
+
     def addModel(self, host_model, reduction=None, collision_cloud_density=1e5, cloud_seed=0):
         """Tracker::addModel (tracker.cpp:59-267): device mirror incl. the 64^3 observation SDF, collision cloud, pose."""
         m_id = len(self.models)
@@ -122,8 +129,6 @@ class Tracker:
         import ctypes as C
         from . import _abi
         from ._abi import check, lib
-        if self.priors:
-            raise NotImplementedError("priors in the observation loop are not wired up yet (device priors live in TrackerNoObs)")
         o, n = self.opts, len(self.models)
         dev = self.prediction.device
         h, w = vert.shape[:2]
@@ -171,8 +176,20 @@ class Tracker:
         if debug:
             info = torch.zeros((max(o.numIterations, 1), n, 8), dtype=torch.float32, device=dev)
             first = torch.zeros(D * D + D, dtype=torch.float32, device=dev)
-        check(lib().dartk_optimize_poses(C.byref(mo), mm, device._ptr(vert), device._ptr(norm), w, h, device._ptr(self.prediction),
-                                         device._ptr(info), device._ptr(first), device._stream()))
+        if self.priors:         # Tracker::addPrior: contact priors evaluated and updated inside the loop (optimizer.cpp:727-732,757-759)
+            from .tracker_no_obs import priors_array
+            arr = priors_array(self.priors)
+            d_pri = torch.empty(C.sizeof(_abi.ContactPriorC) * len(self.priors), dtype=torch.uint8, device=dev)
+            check(lib().dartk_optimize_poses_priors(C.byref(mo), mm, device._ptr(d_pri), arr, len(self.priors), device._ptr(vert),
+                                                    device._ptr(norm), w, h, device._ptr(self.prediction), device._ptr(info),
+                                                    device._ptr(first), device._stream()))
+            back = (_abi.ContactPriorC * len(self.priors)).from_buffer_copy(d_pri.cpu().numpy().tobytes())
+            for p, q in zip(self.priors, back):     # the reference moves the prior objects' contact points
+                if p.update_contact_point:
+                    p.contactPoint = (float(q.contactPoint[0]), float(q.contactPoint[1]), float(q.contactPoint[2]))
+        else:
+            check(lib().dartk_optimize_poses(C.byref(mo), mm, device._ptr(vert), device._ptr(norm), w, h, device._ptr(self.prediction),
+                                             device._ptr(info), device._ptr(first), device._stream()))
         for m in range(n):      # the poses live on the device during the loop; mirror them back once
             T_mc, _, _, _ = self.models[m].get_transforms()
             p = self.poses[m]
@@ -196,7 +213,7 @@ class Tracker:
         from . import _abi
         from ._abi import check, lib
         if self.priors:
-            raise NotImplementedError("priors in the observation loop are not wired up yet (device priors live in TrackerNoObs)")
+            raise NotImplementedError("contact priors carry per-tracker state (their contact points): use optimizePosesDevice per frame")
         o, n = self.opts, len(self.models)
         dev = self.prediction.device
         F_, h, w = vert.shape[0], vert.shape[1], vert.shape[2]
@@ -248,8 +265,8 @@ class Tracker:
 
     # ---- Optimizer::optimizePoses (optimizer.cpp:524-781), host-driven: one C-ABI call per term as the reference drives it
     def optimizePoses(self, vert, norm, debug=False):
-        if self.priors:
-            raise NotImplementedError("priors in the observation loop are not wired up yet (device priors live in TrackerNoObs)")
+        if self.priors:         # the priors are evaluated inside the device-resident loop's solve
+            return self.optimizePosesDevice(vert, norm, debug=debug)
         o = self.opts
         n = len(self.models)
         models, poses = self.models, self.poses

@@ -219,7 +219,8 @@ class TrackerNoObs:
 
     def _ensure(self, batch):
         n = len(self.models)
-        key = (tuple(v > 0 for v in self.opts.lambdaIntersection), len(self.priors), max(batch, self.max_batch))
+        key = (tuple(v > 0 for v in self.opts.lambdaIntersection), len(self.priors), max(batch, self.max_batch),
+               any(p.update_contact_point for p in self.priors))
         if self._handle is not None and key == self._terms_key:
             return
         self.close()
@@ -274,7 +275,7 @@ class TrackerNoObs:
         return 6 + (self.host_models[m].n_joints if self.reductions[m] is None else self.reductions[m].getReducedDimensions())
 
     def _sig(self):
-        return [(p.weight, tuple(p.contactPoint), p.contactThreshold) for p in self.priors]
+        return [(p.weight, tuple(p.contactPoint), p.contactThreshold, p.update_contact_point) for p in self.priors]
 
     def _sync_priors(self):
         psig = [p.sig() for p in self.point_priors]
@@ -311,7 +312,21 @@ class TrackerNoObs:
             self.joints[m] = j_out[0, off:off + nj].copy()
             off += nj
         self.iter_info, self.first_system = (info[0] if info is not None else None), (first[0] if first is not None else None)
+        if any(p.update_contact_point for p in self.priors):       # the reference moves the prior objects' contact points
+            cp = self.getContactPoints(1)[0]
+            for p, q in zip(self.priors, cp):
+                if p.update_contact_point:
+                    p.contactPoint = tuple(float(v) for v in q)
+            self._priors_sig = None
         return float(energy[0])
+
+    def getContactPoints(self, batch):
+        """Contact points [batch, nPriors, 3] of the candidates after the last optimizePoses / optimizePosesBatch call (priors
+        with update_contact_point move, ContactPrior::updatePriorParams, contact_prior.cpp:207-221)."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        out = torch.empty((batch, len(self.priors), 3), dtype=torch.float32, device=dev)
+        check(lib().dartk_noobs_contact_points(self._handle, batch, device._ptr(out), device._stream()))
+        return out.cpu().numpy()
 
     def optimizePosesBatch(self, T_mcs, joints, debug=False, device_arrays=False):
         """`batch` independent candidates: T_mcs [B, nModels, 12], joints [B, sum of joints] (numpy or CUDA tensors).

@@ -281,7 +281,7 @@ typedef struct {
     float normal[3];                      /* _normal_sf */
     int32_t invert;                       /* repulsive */
     float contactThreshold;               /* _contactThreshold */
-    int32_t updateSrc, updateDst, updateContact;   /* updateContact must be 0 on the device path (grasp_analyzer.cpp:359,374,383) */
+    int32_t updateSrc, updateDst, updateContact;   /* _update_src_pose, _update_dst_pose, _update_contact_point */
 } dartk_contact_prior;
 
 /* The OptimizationOptions fields OptimizerNoObs reads (optimization.h:9-72), per model. */
@@ -350,7 +350,14 @@ int dartk_noobs_set_point_priors(dartk_noobs_t t, const dartk_point_prior *h_pri
  * d_firstSystem [batch][D*D + D] = upper JTJ and JTe of iteration 0 before regularisation, D = sum of model dims. */
 int dartk_noobs_optimize_poses(dartk_noobs_t t, const dartk_noobs_options *opts, int batch, float *d_T_mcs,
                                float *d_joints, float *d_energy, float *d_iterInfo, float *d_firstSystem, void *stream);
-/* OptimizerNoObs::getError (optimizer.cpp:985-1076) at the given poses */
+/* Contact priors with update_contact_point (contact_prior.cpp:104-108,151-186): the prior's three contact-point unknowns
+ * are solved with the system (optimizer.cpp:829-832,931), ContactPrior::updatePriorParams (contact_prior.cpp:207-221) moves
+ * the contact point by its share of the update and projectToSdfSurface (sdf.cpp:6-23) puts it back onto its SDF's surface.
+ * The reference mutates the prior object; here every candidate of the batch carries its own copy of the contact points,
+ * started from the priors' at each dartk_noobs_optimize_poses call. This reads them back after that call:
+ * d_contactPoints [batch][nPriors][3] (source-SDF frame). */
+int dartk_noobs_contact_points(dartk_noobs_t t, int batch, float *d_contactPoints, void *stream);
+/* OptimizerNoObs::getError (optimizer.cpp:985-1076) at the given poses (and the priors' own contact points) */
 int dartk_noobs_get_error(dartk_noobs_t t, const dartk_noobs_options *opts, int batch, const float *d_T_mcs,
                           const float *d_joints, float *d_energy, void *stream);
 
@@ -391,6 +398,16 @@ typedef struct dartk_multi_options {
 int dartk_optimize_poses(const dartk_multi_options *opts, const dartk_multi_model *models, const float *d_vert,
                          const float *d_norm, int width, int height, float *d_prediction, float *d_iterInfo,
                          float *d_firstSystem, void *stream);
+
+/* The same with the tracker's contact priors (Tracker::addPrior; optimizer.cpp:727-732: after the model blocks are assembled every
+ * prior adds its contribution, ContactPrior::computeContribution, contact_prior.cpp:8-205, and :757-759: after the pose update
+ * every prior takes its share of the parameter update, ContactPrior::updatePriorParams, contact_prior.cpp:207-221, with
+ * projectToSdfSurface, sdf.cpp:6-23). The tracking loop carries a handful of priors (hand-object contacts): they are evaluated
+ * inside the solve kernel, one after the other. h_priors [nPriors] is uploaded to d_priors [nPriors] (device, caller-owned)
+ * at the start of the call; priors with updateContact leave their moved contact point in d_priors[p].contactPoint. */
+int dartk_optimize_poses_priors(const dartk_multi_options *opts, const dartk_multi_model *models, dartk_contact_prior *d_priors,
+                                const dartk_contact_prior *h_priors, int nPriors, const float *d_vert, const float *d_norm,
+                                int width, int height, float *d_prediction, float *d_iterInfo, float *d_firstSystem, void *stream);
 
 /* Optimizer::optimizePoses (optimizer.cpp:524-781) for nFrames INDEPENDENT frames in one call (BASELINE configs[4]: a batch of
  * recorded frames tracked from their own start poses; the reference would loop over the frames on the host). Every kernel launch

@@ -1049,6 +1049,35 @@ void orc_solve_upper(const float *A, const float *b, int n, float *x) {
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * projectToSdfSurface (sdf.cpp:6-23): gradient steps of the signed distance towards the zero level set, in grid
+ * coordinates. `abs` there is the float overload (sdf.h pulls in <math.h> and <stdlib.h> through SE3.h / grid_3d.h).
+ * normalize() is helper_math's v * (1 / sqrtf(dot(v, v))) on the host.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_project_to_sdf_surface(const orc_grid *sdf, float *pg, float threshold, int maxIters) {
+    for (int iter = 0; iter < maxIters; ++iter) {
+        if (!orc_grid_in_bounds_gradient_interp(sdf, pg)) return;
+        const float dist = orc_grid_value_interp(sdf, pg);
+        if (fabsf(dist) < threshold) return;
+        float grad[3];
+        orc_grid_gradient_interp(sdf, pg, grad);
+        const float invLen = 1.0f / sqrtf(dot3(grad, grad));
+        for (int k = 0; k < 3; ++k) pg[k] = pg[k] - dist * (grad[k] * invLen);
+    }
+}
+
+/* ContactPrior::updatePriorParams (contact_prior.cpp:207-221): the contact point takes its three entries of the parameter
+ * update and is projected back onto the surface of its own (source) SDF; threshold 1e-9, the default 100 iterations. */
+void orc_contact_prior_update_params(orc_contact_prior *p, const float *update, const orc_model *const *models) {
+    if (!p->updateContact) return;
+    for (int k = 0; k < 3; ++k) p->contactPoint[k] += update[k];
+    const orc_grid sdf = model_sdf(models[p->srcModel], p->srcSdf);
+    float g[3];
+    orc_grid_coords(&sdf, p->contactPoint, g);
+    orc_project_to_sdf_surface(&sdf, g, 1e-9f, 100);
+    for (int k = 0; k < 3; ++k) p->contactPoint[k] = sdf.resolution * g[k] + sdf.offset[k];      /* getWorldCoords, grid_3d.h:53-55 */
+}
+
+/* ------------------------------------------------------------------------------------------------
  * contact prior (contact_prior.cpp:8-205)
  * ---------------------------------------------------------------------------------------------- */
 static float contact_prior_contribution_(const orc_contact_prior *p, const orc_model *const *models,

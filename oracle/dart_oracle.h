@@ -185,6 +185,10 @@ float orc_contact_prior_contribution(const orc_contact_prior *p, const orc_model
                                      int priorParamOffset, float *JTJ, int sys, float *JTe,
                                      int32_t *dstSdfOut);
 
+/* projectToSdfSurface (sdf.cpp:6-23) on grid coordinates, and ContactPrior::updatePriorParams (contact_prior.cpp:207-221) */
+void orc_project_to_sdf_surface(const orc_grid *sdf, float *pointGrid, float threshold, int maxIters);
+void orc_contact_prior_update_params(orc_contact_prior *p, const float *update, const orc_model *const *models);
+
 /* ---- keypoint priors (point_3d_3d_prior.cpp:6-69, point_2d_3d_prior.cpp:6-83) ---- */
 typedef struct {
     int32_t kind;               /* 0 Point3D3DPrior, 1 Point2D3DPrior */

@@ -125,6 +125,32 @@ void orc_noobs_set_reductions(const orc_reduction *red) { g_noobsRed = red; }
 static void project_reduced(const orc_model *m, const orc_reduction *r, const float *art, float *full);
 static int noobs_red_type(int m) { return g_noobsRed ? g_noobsRed[m].type : 0; }
 
+/* Offsets of the priors' 3 parameters behind the model blocks (optimizer.cpp:590-593, 829-832: every ContactPrior owns
+ * three, getNumPriorParams). Frozen contact points never receive a non-zero in their rows or columns, so they share one
+ * all-zero slot at the end here instead of three unknowns each. Returns the system size. */
+static int prior_param_offsets(const orc_contact_prior *priors, int nPriors, int D, int *off) {
+    int sys = D, anyFrozen = 0;
+    for (int p = 0; p < nPriors; ++p) {
+        if (priors[p].updateContact) { off[p] = sys; sys += 3; }
+        else { off[p] = -1; anyFrozen = 1; }
+    }
+    if (anyFrozen || nPriors == 0) { for (int p = 0; p < nPriors; ++p) if (off[p] < 0) off[p] = sys; sys += 3; }
+    return sys;
+}
+/* where the loops leave the contact points of their priors after the last iteration ([nPriors][3]; the reference mutates the
+ * prior objects, contact_prior.cpp:212-219), or NULL */
+static float *g_contactOut = NULL;
+void orc_set_contact_out(float *out) { g_contactOut = out; }
+static orc_contact_prior *priors_copy(const orc_contact_prior *priors, int nPriors) {
+    orc_contact_prior *c = (orc_contact_prior *)malloc(sizeof(orc_contact_prior) * (size_t)(nPriors > 0 ? nPriors : 1));
+    if (nPriors > 0) memcpy(c, priors, sizeof(orc_contact_prior) * (size_t)nPriors);
+    return c;
+}
+static void contacts_out(const orc_contact_prior *priors, int nPriors) {
+    if (!g_contactOut) return;
+    for (int p = 0; p < nPriors; ++p) for (int k = 0; k < 3; ++k) g_contactOut[3 * p + k] = priors[p].contactPoint[k];
+}
+
 typedef struct {
     int n, D, sys, nPriors;
     float *full[ORC_MAX_MODELS];     /* full joint vectors (projection of the reduced articulation) */
@@ -145,14 +171,7 @@ static void noobs_init(noobs_ctx *c, const orc_model *const *models, int n, cons
         c->T_cm[m] = (float *)malloc(sizeof(float) * 12);
     }
     c->priorOff = (int *)malloc(sizeof(int) * (size_t)(nPriors > 0 ? nPriors : 1));
-    int sys = c->D, anyFrozen = 0;
-    for (int p = 0; p < nPriors; ++p) {
-        if (priors[p].updateContact) { c->priorOff[p] = sys; sys += 3; }
-        else { c->priorOff[p] = -1; anyFrozen = 1; }
-    }
-    /* frozen contact points share one all-zero 3-parameter slot (their rows never receive a non-zero) */
-    if (anyFrozen) { for (int p = 0; p < nPriors; ++p) if (c->priorOff[p] < 0) c->priorOff[p] = sys; sys += 3; }
-    c->sys = sys;
+    c->sys = prior_param_offsets(priors, nPriors, c->D, c->priorOff);
 }
 static void noobs_free(noobs_ctx *c) {
     for (int m = 0; m < c->n; ++m) { free(c->T_mf[m]); free(c->T_fm[m]); free(c->T_cm[m]); free(c->full[m]); }
@@ -239,6 +258,8 @@ float orc_optimize_poses_noobs(const orc_model *const *models, float *const *T_m
                                const int32_t *const *potentials, const orc_contact_prior *priors, int nPriors,
                                float *iterInfo, float *firstSystem) {
     noobs_ctx c;
+    orc_contact_prior *mp = priors_copy(priors, nPriors);      /* updatePriorParams moves the contact points */
+    priors = mp;
     noobs_init(&c, models, o->nModels, priors, nPriors);
     const int sysN = c.sys, D = c.D;
     float *JTJ = (float *)malloc(sizeof(float) * (size_t)sysN * sysN);
@@ -297,6 +318,8 @@ float orc_optimize_poses_noobs(const orc_model *const *models, float *const *T_m
                     joints[m][i] = fminf(fmaxf(g_noobsRed[m].mins[i], joints[m][i] + x[c.offs[m] + 6 + i]), g_noobsRed[m].maxs[i]);
             }
         }
+        for (int p = 0; p < nPriors; ++p) /* optimizer.cpp:956-958 */
+            orc_contact_prior_update_params(&mp[p], x + c.priorOff[p], models);
         if (iterInfo) {
             float *r = iterInfo + 8 * it;
             r[0] = eInt; r[1] = ePri; r[2] = (float)nActive; r[3] = r[4] = r[5] = r[6] = r[7] = 0;
@@ -304,7 +327,10 @@ float orc_optimize_poses_noobs(const orc_model *const *models, float *const *T_m
     }
     free(JTJ); free(JTe); free(x);
     noobs_free(&c);
-    return orc_get_error_noobs(models, T_mcs, joints, o, clouds, nClouds, potentials, priors, nPriors);
+    contacts_out(mp, nPriors);
+    const float err = orc_get_error_noobs(models, T_mcs, joints, o, clouds, nClouds, potentials, mp, nPriors);
+    free(mp);
+    return err;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -348,7 +374,10 @@ void orc_optimize_poses(const orc_model *const *models, float *const *T_mcs, flo
         obs[m].resolution = models[m]->obs_sdf_resolution;
         obs[m].data = obsSdf ? obsSdf[m] : NULL;
     }
-    const int sysN = D + 3;          /* frozen contact points share one all-zero parameter slot (see noobs_init) */
+    orc_contact_prior *mp = priors_copy(priors, nPriors);      /* updatePriorParams moves the contact points (:757-759) */
+    priors = mp;
+    int *priorOff = (int *)malloc(sizeof(int) * (size_t)(nPriors > 0 ? nPriors : 1));
+    const int sysN = prior_param_offsets(priors, nPriors, D, priorOff);
     float *JTJ = (float *)malloc(sizeof(float) * (size_t)sysN * sysN);
     float *JTe = (float *)malloc(sizeof(float) * (size_t)sysN);
     float *x = (float *)malloc(sizeof(float) * (size_t)sysN);
@@ -444,7 +473,7 @@ void orc_optimize_poses(const orc_model *const *models, float *const *T_mcs, flo
             free(eJ); free(J);
         }
         for (int p = 0; p < nPriors; ++p) /* :727-730 */
-            orc_contact_prior_contribution(&priors[p], models, cT_mc, cT_cm, cT_fm, cT_mf, offs, rdims, D, JTJ, sysN, JTe, NULL);
+            orc_contact_prior_contribution(&priors[p], models, cT_mc, cT_cm, cT_fm, cT_mf, offs, rdims, priorOff[p], JTJ, sysN, JTe, NULL);
         if (it == 0 && firstSystem) {
             for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) firstSystem[i * D + j] = JTJ[i * sysN + j];
             for (int i = 0; i < D; ++i) firstSystem[D * D + i] = JTe[i];
@@ -463,7 +492,10 @@ void orc_optimize_poses(const orc_model *const *models, float *const *T_mcs, flo
                 art[m][i] = fminf(fmaxf(lo, art[m][i] + x[offs[m] + 6 + i]), hi);
             }
         }
+        for (int p = 0; p < nPriors; ++p) orc_contact_prior_update_params(&mp[p], x + priorOff[p], models);     /* :757-759 */
     }
+    contacts_out(mp, nPriors);
+    free(mp); free(priorOff);
     for (int m = 0; m < n; ++m) { free(T_mf[m]); free(T_fm[m]); free(T_cm[m]); free(T_obs[m]); free(full[m]); free(pts[m]); }
     free(JTJ); free(JTe); free(x); free(sys); free(pred); free(T_mc_flat);
 }

@@ -91,6 +91,10 @@ float orc_get_error_noobs(const orc_model *const *models, float *const *T_mcs, f
                           const orc_noobs_options *o, const float *const *clouds, const int32_t *nClouds,
                           const int32_t *const *potentials, const orc_contact_prior *priors, int nPriors);
 
+/* orc_optimize_poses_noobs / orc_optimize_poses write the contact points of their priors after the last iteration here
+ * ([nPriors][3]; priors with update_contact_point move, contact_prior.cpp:207-221). The pointer is kept; NULL clears it. */
+void orc_set_contact_out(float *out);
+
 #ifdef __cplusplus
 }
 #endif

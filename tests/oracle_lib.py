@@ -350,6 +350,57 @@ def get_error_noobs(oms, T_mcs, joints, opts_struct, clouds, potentials, priors)
     return float(lib().orc_get_error_noobs(models, T_ptrs, j_ptrs, C.byref(o), c_ptrs, counts, p_ptrs, arr, len(priors)))
 
 
+def contact_prior_contribution(oms, prior, T_mcs, T_cms, T_fms, T_mfs, offs, dims, prior_off, JTJ, JTe):
+    """orc_contact_prior_contribution: adds one prior into the dense row-major JTJ [sys, sys] / JTe [sys] (float32, in place) with
+    its three contact-point unknowns at prior_off; returns (_error, destination SDF)."""
+    from dart_amd.tracker_no_obs import priors_array
+    n = len(oms)
+    arr = priors_array([prior], OrcContactPrior)
+    models = (C.POINTER(OrcModel) * n)(*[C.pointer(o.desc) for o in oms])
+    keep = [[c32(x[m]) for m in range(n)] for x in (T_mcs, T_cms, T_fms, T_mfs)]
+    ptrs = [(fp * n)(*[f(t) for t in k]) for k in keep]
+    o_arr = (C.c_int32 * n)(*[int(v) for v in offs])
+    d_arr = (C.c_int32 * n)(*[int(v) for v in dims])
+    ds = C.c_int32(-1)
+    assert JTJ.dtype == F and JTe.dtype == F and JTJ.flags.c_contiguous
+    lib().orc_contact_prior_contribution.restype = C.c_float
+    e = lib().orc_contact_prior_contribution(C.byref(arr[0]), models, ptrs[0], ptrs[1], ptrs[2], ptrs[3], o_arr, d_arr, int(prior_off),
+                                             f(JTJ), int(JTJ.shape[0]), f(JTe), C.byref(ds))
+    return float(e), int(ds.value)
+
+
+class contact_out:
+    """with contact_out(n_priors) as co: the oracle's optimisation loops leave the contact points of their priors in co.points
+    [n_priors, 3] (priors with update_contact_point move, contact_prior.cpp:207-221)."""
+
+    def __init__(self, n):
+        self.points = np.zeros((max(n, 1), 3), dtype=F)
+
+    def __enter__(self):
+        lib().orc_set_contact_out(f(self.points))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_contact_out(None)
+        return False
+
+
+def project_to_sdf_surface(grid, point_grid, threshold=1e-5, max_iters=100):
+    """orc_project_to_sdf_surface (sdf.cpp:6-23) on grid coordinates; returns the projected point."""
+    p = c32(point_grid).copy()
+    lib().orc_project_to_sdf_surface(C.byref(grid), f(p), C.c_float(threshold), int(max_iters))
+    return p
+
+
+def contact_prior_update_params(oms, prior, update):
+    """orc_contact_prior_update_params (contact_prior.cpp:207-221); returns the new contact point."""
+    from dart_amd.tracker_no_obs import priors_array
+    arr = priors_array([prior], OrcContactPrior)
+    models = (C.POINTER(OrcModel) * len(oms))(*[C.pointer(o.desc) for o in oms])
+    lib().orc_contact_prior_update_params(C.byref(arr[0]), f(c32(update)), models)
+    return np.array(list(arr[0].contactPoint), dtype=F)
+
+
 # ---------------------------------------------------------------------------------------------- Optimizer::optimizePoses
 class OrcReduction(C.Structure):
     _fields_ = [("type", C.c_int32), ("redArt", C.c_int32), ("A", fp), ("b", fp), ("mapping", ip), ("mins", fp), ("maxs", fp)]
@@ -379,9 +430,9 @@ class OrcMultiOptions(C.Structure):
                 ("predFl", C.c_float * 2)]
 
 
-def optimize_poses(tracker, vert, norm, T_mcs, arts):
-    """orc_optimize_poses on the state of a dart_amd.tracker.Tracker (models, reductions, clouds, options).
-    Returns (T_mcs, reduced articulations, iter_info [it, model, 8], first_system)."""
+def optimize_poses(tracker, vert, norm, T_mcs, arts, priors=()):
+    """orc_optimize_poses on the state of a dart_amd.tracker.Tracker (models, reductions, clouds, options) and the contact
+    priors `priors` (optimizer.cpp:727-732). Returns (T_mcs, reduced articulations, iter_info [it, model, 8], first_system)."""
     n = len(tracker.models)
     oms = [OModel(tracker.host_models[m], m, tracker.models[m].obs_layout) for m in range(n)]
     models = (C.POINTER(OrcModel) * n)(*[C.pointer(o.desc) for o in oms])
@@ -435,8 +486,10 @@ def optimize_poses(tracker, vert, norm, T_mcs, arts):
     info = np.zeros((max(mo.numIterations, 1), n, 8), dtype=F)
     first = np.zeros(D * D + D, dtype=F)
     h, w = vert.shape[:2]
+    from dart_amd.tracker_no_obs import priors_array
+    parr = priors_array(list(priors), OrcContactPrior)
     lib().orc_optimize_poses(models, T_ptrs, a_ptrs, reds, C.byref(mo), f(c32(vert)), f(c32(norm)), w, h, c_ptrs, counts, p_ptrs,
-                             None, 0, obs_ptrs, f(info), f(first))
+                             parr if len(priors) else None, len(priors), obs_ptrs, f(info), f(first))
     return T_keep, [a_keep[m][:len(arts[m])] for m in range(n)], info, first
 
 

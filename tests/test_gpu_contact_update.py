@@ -1,0 +1,227 @@
+"""GPU parity for contact priors that move their contact point: update_contact_point = true
+(contact_prior.cpp:104-108,151-186), ContactPrior::updatePriorParams (:207-221), projectToSdfSurface (sdf.cpp:6-23), on
+  * the NoObs path (dartk_noobs_optimize_poses, optimizer.cpp:913-958), single candidates and a batch, and
+  * the observation loop (dartk_optimize_poses_priors, optimizer.cpp:727-732, 757-759),
+against the CPU oracle, which tests/test_oracle_contact_update.py pins against an independent assembly of the reference's
+full system. Poses AND contact points are compared."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from dart_amd import configs, se3
+from dart_amd.optimizer import synthetic_observation
+from dart_amd.tracker_no_obs import ContactPrior
+from test_gpu_optimize_pose import pose_diff
+from test_oracle_contact_update import scene
+
+F = np.float32
+pytestmark = pytest.mark.gpu
+
+
+def with_points(priors, cps):
+    return [type(p)(**{**p.__dict__, "contactPoint": tuple(float(v) for v in cps[k])}) for k, p in enumerate(priors)]
+
+
+def noobs_tracker(sc, priors, max_batch=4):
+    sc2 = type(sc)(**{**sc.__dict__, "priors": priors})
+    return configs.make_grasp_tracker(sc2, max_batch=max_batch)
+
+
+def test_noobs_contact_points_move_as_in_the_oracle(gpu):
+    from trajectory import segmented_parity
+    sc, oms, priors = scene(n_update=4)
+    upd = [k for k, p in enumerate(priors) if p.update_contact_point]
+    assert len(upd) >= 3
+    tr = noobs_tracker(sc, priors)
+    clouds = [c.cpu().numpy() for c in tr.clouds]
+    pots = [p.cpu().numpy() for p in tr.potentials]
+    T0 = np.stack([sc.init_T_mc[0], se3.identity()])[None].astype(F)
+    J0 = sc.init_joints[:1].astype(F)
+    cp0 = np.stack([np.asarray(p.contactPoint, dtype=F) for p in priors])
+
+    # one iteration: poses, energy and every contact point
+    tr.getOptions().numIterations = 1
+    gT, gj, ge, ginfo, gfirst = tr.optimizePosesBatch(T0, J0, debug=True)
+    gcp = tr.getContactPoints(1)[0]
+    o = tr._options_struct()
+    with O.contact_out(len(priors)) as co:
+        oT, oj, oe, oinfo, ofirst = O.optimize_poses_noobs(oms, [T0[0, 0], T0[0, 1]], [J0[0], np.zeros(0, dtype=F)], o, clouds, pots, priors)
+        ocp = co.points.copy()
+    D = 32
+    nref = np.linalg.norm(ofirst[:D * D].astype(np.float64))
+    assert np.linalg.norm(gfirst[0][:D * D].astype(np.float64) - ofirst[:D * D]) / nref < 1e-4
+    assert max(pose_diff(gT[0, 0], oT[0])) < 1e-4 and np.abs(gj[0] - oj[0]).max() < 1e-4
+    assert abs(ge[0] - oe) < 1e-4 * max(1.0, abs(oe))
+    moved = np.abs(ocp - cp0).max(1)
+    assert all(moved[k] == 0 for k in range(len(priors)) if k not in upd) and sum(moved[k] > 1e-6 for k in upd) >= 2
+    print("contact points: max |gpu - oracle| = %.3g m, largest move %.3g m" % (np.abs(gcp - ocp).max(), moved.max()))
+    assert np.abs(gcp - ocp).max() < 1e-5
+    frozen_rows = [k for k in range(len(priors)) if k not in upd]
+    assert np.array_equal(gcp[frozen_rows], cp0[frozen_rows])
+
+    # the trajectory, segment by segment; the state carried between segments includes the contact points
+    def gpu_prefix(k):
+        tr.getOptions().numIterations = k
+        gT, gj, ge, ginfo, _ = tr.optimizePosesBatch(T0, J0, debug=True)
+        return (gT[0, 0].copy(), gT[0, 1].copy(), gj[0].copy(), tr.getContactPoints(1)[0].copy() if k > 0 else cp0.copy()), ginfo[0].copy()
+
+    def oracle_from(pose, k0, n):
+        tr.getOptions().numIterations = n
+        o_ = tr._options_struct()
+        with O.contact_out(len(priors)) as co:
+            oT, oj, oe, oinfo, _ = O.optimize_poses_noobs(oms, [pose[0], pose[1]], [pose[2], np.zeros(0, dtype=F)], o_, clouds, pots,
+                                                          with_points(priors, pose[3]))
+            cps = co.points.copy()
+        return (oT[0], oT[1], oj[0], cps), oinfo
+
+    def decisions_equal(g, o_):
+        return bool(abs(g[1] - o_[1]) <= 5e-2 + 2e-4 * abs(o_[1]) and abs(g[0] - o_[0]) <= 1e-4 * abs(o_[0]) + 1e-7)
+
+    def pose_err(a, b):
+        return max(*pose_diff(a[0], b[0]), *pose_diff(a[1], b[1]), float(np.abs(a[2] - b[2]).max()), float(np.abs(a[3] - b[3]).max()))
+
+    segmented_parity("NoObs with moving contact points", 10, gpu_prefix, oracle_from, decisions_equal, pose_err, bar=1e-3)
+
+
+def test_noobs_batch_candidates_carry_their_own_contact_points(gpu):
+    sc, oms, priors = scene(n_update=3)
+    sc4 = configs.contact_grasp_scene(4, n_attract=24, n_repulse=40, iterations=1)
+    tr = noobs_tracker(sc, priors, max_batch=4)
+    T = np.zeros((4, 2, 12), dtype=F)
+    T[:, 0] = sc4.init_T_mc
+    T[:, 1] = se3.identity()
+    J = sc4.init_joints.astype(F)
+    J[1:] = 0.7 * sc.init_joints[0] + 0.3 * J[1:]          # keep the fingers near the object so that the priors are live
+    tr.getOptions().numIterations = 4
+    bT, bj, be, _, _ = tr.optimizePosesBatch(T, J)
+    bcp = tr.getContactPoints(4)
+    differ = 0
+    for c in range(4):
+        sT, sj, se_, _, _ = tr.optimizePosesBatch(T[c:c + 1], J[c:c + 1])
+        scp = tr.getContactPoints(1)[0]
+        assert np.abs(sT[0] - bT[c]).max() < 1e-5 and np.abs(sj[0] - bj[c]).max() < 1e-5 and abs(se_[0] - be[c]) < 1e-4 * max(1, abs(be[c]))
+        assert np.abs(scp - bcp[c]).max() < 1e-6
+        differ += int(np.abs(bcp[c] - bcp[0]).max() > 1e-6)
+    assert differ >= 1                                      # different candidates moved their contact points differently
+    # the single-candidate call writes the moved points back into the prior objects, as the reference mutates them
+    tr.setPose(0, T[0, 0], J[0]); tr.setPose(1, T[0, 1], np.zeros(0, dtype=F))
+    before = [p.contactPoint for p in tr.priors]
+    tr.optimizePoses()
+    after = [p.contactPoint for p in tr.priors]
+    assert any(a != b for a, b, p in zip(after, before, tr.priors) if p.update_contact_point)
+    assert all(a == b for a, b, p in zip(after, before, tr.priors) if not p.update_contact_point)
+    assert np.abs(np.asarray(after, dtype=F) - bcp[0]).max() < 1e-6
+
+
+def multi_scene(width=320, height=180):
+    """Config 5 (Barrett 8->4 + object, observation terms) with hand -> object contact priors on the finger links that move
+    their contact points, and object -> hand priors with frozen ones."""
+    sc = configs.config5(width, height, 0)
+    tr = configs.make_multi_tracker(sc)
+    hand, obj = sc.hand, sc.obj
+    # the object among the Barrett fingers (config 5 itself keeps the two apart): true poses, then the observation of them
+    T_mc_h, art = sc.true[0]
+    full = np.zeros(8, dtype=F)
+    sc.reduction.projectReducedToFull(art, full)
+    T_mf = hand.forward_kinematics(full, "dh")
+    cloud = hand.collision_cloud(2e4, seed=3)
+    pts_m = np.zeros((len(cloud), 3), dtype=F)
+    for sn in np.unique(cloud[:, 3].astype(int)):
+        sel = cloud[:, 3].astype(int) == sn
+        pts_m[sel] = se3.apply(T_mf[hand.sdf_frame[int(sn)]], cloud[sel, :3])
+    centre = pts_m.mean(0) + np.array([0.0, 0.0, 0.02], dtype=F)
+    T_mc_o = se3.mul(se3.translation(*(-centre)), T_mc_h)
+    sc.true = [(T_mc_h, art), (T_mc_o, np.zeros(0, dtype=F))]
+    rng = np.random.default_rng(4)
+    sc.init = []
+    for T, a_ in sc.true:
+        t6 = np.concatenate([rng.uniform(-0.006, 0.006, 3), rng.uniform(-0.03, 0.03, 3)]).astype(F)
+        sc.init.append((se3.mul(se3.exp(t6), T), np.clip(a_ + rng.uniform(-0.05, 0.05, len(a_)).astype(F),
+                                                        [sc.reduction.getMin(i) for i in range(len(a_))],
+                                                        [sc.reduction.getMax(i) for i in range(len(a_))]).astype(F) if len(a_) else a_))
+    for m, (T, a_) in enumerate(sc.true):
+        tr.getPose(m).setTransformCameraToModel(T)
+        tr.getPose(m).getReducedArticulation()[:] = a_
+        tr.updatePose(m)
+    _, vert, norm = synthetic_observation(tr.models, sc.width, sc.height, sc.fl, sc.pp)
+    # points of the hand's collision cloud closest to the object: contact points on their own SDFs' surfaces
+    a = np.asarray(configs.OBJ_RADII, dtype=np.float64)
+    priors = []
+    for s_ in np.unique(cloud[:, 3].astype(int)):
+        sel = cloud[:, 3].astype(int) == s_
+        po = (pts_m[sel] - centre).astype(np.float64)
+        lvl = np.abs(np.sqrt(((po / a) ** 2).sum(1)) - 1.0) * a.min()
+        k = int(np.argmin(lvl))
+        if lvl[k] < 0.03:
+            priors.append(ContactPrior(0, 1, int(s_), -1, 30.0, tuple(cloud[sel][k, :3]), True, True, True, False, 0.04))
+    rng = np.random.default_rng(9)
+    v = rng.normal(size=(6, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    for q in v * a:
+        priors.append(ContactPrior(1, 0, 0, -1, 10.0, tuple(q.astype(F)), False, True, True, False, 0.05))
+    assert sum(p.update_contact_point for p in priors) >= 2
+    for p in priors:
+        tr.addPrior(p)
+    return sc, tr, vert, norm, priors
+
+
+def test_observation_loop_with_contact_priors_matches_oracle(gpu):
+    sc, tr, vert, norm, priors = multi_scene()
+    cp0 = np.stack([np.asarray(p.contactPoint, dtype=F) for p in priors])
+    init_T, init_a = [T for T, _ in sc.init], [a for _, a in sc.init]
+    v_np, n_np = vert.cpu().numpy(), norm.cpu().numpy()
+
+    def reset():
+        for m in range(2):
+            tr.getPose(m).setTransformCameraToModel(init_T[m])
+            tr.getPose(m).getReducedArticulation()[:] = init_a[m]
+        for p, q in zip(tr.priors, cp0):
+            p.contactPoint = tuple(float(x) for x in q)
+
+    # the priors change the system: first system with and without them, each against the oracle
+    for use_priors in (False, True):
+        reset()
+        tr.priors = list(priors) if use_priors else []
+        tr.getOptions().numIterations = 1
+        tr.optimizePosesDevice(vert, norm, debug=True)
+        first = tr.first_system.copy()
+        if not use_priors:
+            first_without = first
+        reset()                                                 # the call moved the prior objects' contact points
+        _, _, oinfo, ofirst = O.optimize_poses(tr, v_np, n_np, init_T, init_a, priors if use_priors else ())
+        print("priors %s: counts gpu %s oracle %s" % (use_priors, tr.iteration_summaries[0, :, 3:5].tolist(), oinfo[0, :, 3:5].tolist()))
+        assert np.array_equal(tr.iteration_summaries[0, :, 3:5], oinfo[0, :, 3:5])
+        D = 16
+        # J^T J of the models as the oracle's; J^T e only without priors: with them the device loop has already taken the contact
+        # points' share of the back substitution out of the right-hand side (the oracle does that inside its solve)
+        for sl in (slice(0, D * D), slice(D * D, D * D + D))[:1 if use_priors else 2]:
+            nref = np.linalg.norm(ofirst[sl].astype(np.float64))
+            assert np.linalg.norm(first[sl].astype(np.float64) - ofirst[sl]) / nref < 1e-4
+        if use_priors:
+            cross = first[:D * D].reshape(D, D)[:10, 10:]       # hand x object block: only the priors couple the models
+            assert np.abs(cross).max() > 0 and np.abs(first - first_without).max() > 1e-3
+        else:
+            assert not first[:D * D].reshape(D, D)[:10, 10:].any()
+    tr.priors = list(priors)
+    for iters in (1, 4):
+        reset()
+        tr.getOptions().numIterations = iters
+        tr.optimizePoses(vert, norm, debug=True)            # routes to the device loop when priors are present
+        gT = [tr.getPose(m).getTransformCameraToModel().copy() for m in range(2)]
+        ga = [tr.getPose(m).getReducedArticulation().copy() for m in range(2)]
+        gcp = np.stack([np.asarray(p.contactPoint, dtype=F) for p in tr.priors])
+        ginfo = tr.iteration_summaries.copy()
+        reset()
+        with O.contact_out(len(priors)) as co:
+            oT, oa, oinfo, _ = O.optimize_poses(tr, v_np, n_np, init_T, init_a, priors)
+            ocp = co.points.copy()
+        same = np.array_equal(ginfo[:, :, 3:5], oinfo[:, :, 3:5])
+        err = max(max(pose_diff(gT[m], oT[m])) for m in range(2))
+        err = max(err, float(np.abs(ga[0] - oa[0]).max()), float(np.abs(gcp - ocp).max()))
+        moved = np.abs(ocp - cp0).max(1)
+        print("observation loop + priors, %d iterations: counts equal %s, max pose / contact point difference %.3g, contact points moved up to %.3g m"
+              % (iters, same, err, moved.max()))
+        assert same, "association / prediction counts differ from the oracle's: compare segment by segment instead"
+        assert err < 1e-3
+        upd = [k for k, p in enumerate(priors) if p.update_contact_point]
+        assert sum(moved[k] > 1e-6 for k in upd) >= 2 and all(moved[k] == 0 for k in range(len(priors)) if k not in upd)
+    reset()
