@@ -175,11 +175,20 @@ def test_edge_cases(gpu):
     T1, j1 = configs.grasp_batch_arrays(sc2)
     e = tr2.getError(T1, j1)
     assert abs(e - (2.0 * 0.02 - 3.0 * 0.02 + 0.0) / 3.0) < 1e-7
-    # update_contact_point is rejected loudly (not silently ignored)
-    sc2.priors = [ContactPrior(1, 0, 0, -1, 1.0, (0, 0, 0.06), True, True, True, False, 0.02)]
+    # a prior between a model and itself is rejected loudly (its source and destination blocks would alias)
+    sc2.priors = [ContactPrior(0, 0, 0, -1, 1.0, (0, 0, 0.06), False, True, True, False, 0.02)]
     tr3 = configs.make_grasp_tracker(sc2)
     with pytest.raises(_abi.DartkError):
         tr3.getError(T1, j1)
+    # update_contact_point: getError alone never moves a contact point (tests/test_gpu_contact_update.py covers the moves)
+    sc2.priors = [ContactPrior(1, 0, 0, -1, 1.0, (0, 0, 0.06), True, True, True, False, 0.02)]
+    tr4 = configs.make_grasp_tracker(sc2)
+    o4 = tr4.getOptions()
+    o4.lambdaIntersection = [0.0] * (n * n)
+    sc2.priors = [ContactPrior(1, 0, 0, -1, 1.0, (0, 0, 0.06), False, True, True, False, 0.02)]
+    tr5 = configs.make_grasp_tracker(sc2)
+    tr5.getOptions().lambdaIntersection = [0.0] * (n * n)
+    assert tr4.getError(T1, j1) == tr5.getError(T1, j1)
 
 
 def test_full_size_batch_properties(gpu):
