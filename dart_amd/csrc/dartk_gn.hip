@@ -9,6 +9,9 @@
 #include "dartk_reduce.h"
 #include "dartk_kernels.h"
 #include "dartk_fk.h"
+#include "dartk_raycast.h"
+
+#include <cstdlib>
 
 #include <vector>
 
@@ -89,15 +92,23 @@ valid_write_kernel(const float4 *__restrict__ vert, int nPix, const int *__restr
 }
 
 // One tile of NE_BLOCK valid pixels per workgroup; workgroups past the end of the list exit (their slab is never read).
+struct FusedObs2ModArgs {
+    const float4 *vert, *norm;
+    const int *validIdx, *nValidPtr;
+    float distThr, normThr, planeOffset, pnx, pny, pnz, huberDelta;
+    float *slabs;
+    int *count;
+};
 template <int PPT>
-__global__ void __launch_bounds__(NE_BLOCK)
-fused_obs2mod_kernel(const float4 *__restrict__ vert, const float4 *__restrict__ norm, const int *__restrict__ validIdx,
-                     const int *__restrict__ nValidPtr, ModelView m,
-                     float distThr, float normThr, float planeOffset, float pnx, float pny, float pnz, float huberDelta,
-                     float *__restrict__ slabs, int *__restrict__ count) {
-    extern __shared__ float lds[];
-    const int nValid = *nValidPtr;
-    if ((int)blockIdx.x * NE_BLOCK >= nValid) return;
+__device__ __forceinline__ void fused_obs2mod_tile(int tile, const FusedObs2ModArgs &fa, const ModelView &m, float *lds) {
+    const float4 *__restrict__ vert = fa.vert, *__restrict__ norm = fa.norm;
+    const int *__restrict__ validIdx = fa.validIdx;
+    const float distThr = fa.distThr, normThr = fa.normThr, planeOffset = fa.planeOffset, pnx = fa.pnx, pny = fa.pny, pnz = fa.pnz;
+    const float huberDelta = fa.huberDelta;
+    float *__restrict__ slabs = fa.slabs;
+    int *__restrict__ count = fa.count;
+    const int nValid = *fa.nValidPtr;
+    if (tile * NE_BLOCK >= nValid) return;
     const int d = 6 + m.nJoints;
     const int ld = row_len(d, false);
     float *sT_fm = lds;
@@ -111,7 +122,7 @@ fused_obs2mod_kernel(const float4 *__restrict__ vert, const float4 *__restrict__
 
     PairAcc<NE_BLOCK, PPT> acc;
     acc.init(d, false);
-    const int k = blockIdx.x * NE_BLOCK + threadIdx.x;
+    const int k = tile * NE_BLOCK + threadIdx.x;
     bool active = false;
     AssocResult r;
     f3 gf; gf.x = gf.y = gf.z = 0.f;
@@ -161,8 +172,35 @@ fused_obs2mod_kernel(const float4 *__restrict__ vert, const float4 *__restrict__
     }
     __syncthreads();
     if (nActive) acc.accumulate(rows, ld, nActive);
-    acc.store(slabs + (size_t)blockIdx.x * sys_size(d), sys_size(d));
+    acc.store(slabs + (size_t)tile * sys_size(d), sys_size(d));
     if (threadIdx.x == 0 && nActive) atomicAdd(count, nActive);
+}
+template <int PPT>
+__global__ void __launch_bounds__(NE_BLOCK)
+fused_obs2mod_kernel(FusedObs2ModArgs fa, ModelView m) {
+    extern __shared__ float lds[];
+    fused_obs2mod_tile<PPT>(blockIdx.x, fa, m, lds);
+}
+
+// The ray-cast trace and the obs->mod term in ONE launch. Both need only the pose the solve just wrote and neither needs the
+// other, so they used to run side by side on two streams -- and every fork and join of the two streams cost the iteration's
+// critical chain ~6 us of event handling (profiles/r02_timeline.txt), a quarter of a whole kernel. As one grid (workgroups
+// [0, nTraceWgs) walk the trace tasks, the rest take one tile of valid pixels each) they still run side by side, the whole
+// iteration stays on ONE stream, and kernels that follow each other on one stream start back to back.
+struct TraceArgs { float flx, fly, ppx, ppy; int width, height; float2 *trace; int nTraceWgs; };
+template <int PPT>
+__global__ void __launch_bounds__(NE_BLOCK)
+trace_and_obs2mod_kernel(TraceArgs ta, FusedObs2ModArgs fa, ModelView m) {
+    extern __shared__ float lds[];
+    if ((int)blockIdx.x < ta.nTraceWgs) {       // the trace's stragglers are the launch's critical path: first in the grid
+        int *sR = reinterpret_cast<int *>(lds);
+        stage_ray_rects(m, 0.0f, ta.flx, ta.fly, ta.ppx, ta.ppy, ta.width, ta.height, sR);
+        constexpr int W = NE_BLOCK / 64;
+        raycast_trace_tasks(blockIdx.x * W + (threadIdx.x >> 6), ta.nTraceWgs * W, sR, ta.flx, ta.fly, ta.ppx, ta.ppy, ta.width, ta.height, m,
+                            ta.trace, 0.0f);
+        return;
+    }
+    fused_obs2mod_tile<PPT>(blockIdx.x - ta.nTraceWgs, fa, m, lds);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -717,7 +755,16 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     // iteration's critical path never waits on a cross-stream event; the shorter obs->mod chain takes the side stream
     // and has finished long before the join.
     const bool fork = useA && useB && o->numIterations > 0;
-    hipStream_t stB = st, stA = fork ? ws->auxStream : st, stO = fork ? ws->auxStream2 : st;
+    // With both terms on, the trace and the obs->mod term share one launch on the caller's stream (trace_and_obs2mod_kernel):
+    // the iteration then needs no fork and no join at all. The side stream is left for the self-intersection term, if any.
+#ifdef DARTK_STAMPS
+    const bool unionAB = false;         // the diagnostic build keeps the trace in its own kernel (its counters live there)
+#else
+    static const bool noUnion = getenv("DARTK_NO_UNION_LAUNCH") != nullptr;            // diagnostic: the two-stream form
+    const bool unionAB = fork && !noUnion && m.nSdfs <= NE_BLOCK && m.nSdfs <= kMaxRaySdfs;
+#endif
+    const bool sideA = fork && (!unionAB || useC);
+    hipStream_t stB = st, stA = sideA ? ws->auxStream : st, stO = fork ? ws->auxStream2 : st;
     DARTK_HIP(hipMemsetAsync(ws->counters, 0, 2 * sizeof(int), st));      // before the fork; later iterations: zeroed by the solve kernel
     // an error return after a fork must leave the caller's stream ordered after the side streams: they write the slab, index
     // and system buffers of this workspace, which the next call on `st` reuses
@@ -731,7 +778,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     } joinGuard{ws, st, stA, stO, false};
     if (fork) {
         DARTK_HIP(hipEventRecord(ws->evFork, st));
-        DARTK_HIP(hipStreamWaitEvent(stA, ws->evFork, 0));
+        if (sideA) DARTK_HIP(hipStreamWaitEvent(stA, ws->evFork, 0));
         DARTK_HIP(hipStreamWaitEvent(stO, ws->evFork, 0));
         joinGuard.on = true;
     }
@@ -750,47 +797,74 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     if (ldsS > 64 * 1024)
         DARTK_HIP(hipFuncSetAttribute((const void *)gn_solve_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS));
 
+    hipStream_t stV = unionAB ? st : stA;        // the valid-pixel list is read by the obs->mod tiles, wherever they run
     if (useA && o->numIterations > 0) {
-        ProfScope ps(DARTK_PROF_OTHER, stA);
-        hipLaunchKernelGGL(valid_count_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, stA, (const float4 *)d_vert, nPix, vcOffsets);
-        hipLaunchKernelGGL(valid_scan_kernel, dim3(1), dim3(1024), 0, stA, vcOffsets, nVcBlocks, d_nValid);
-        hipLaunchKernelGGL(valid_write_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, stA, (const float4 *)d_vert, nPix, vcOffsets, validIdx);
+        ProfScope ps(DARTK_PROF_OTHER, stV);
+        hipLaunchKernelGGL(valid_count_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, stV, (const float4 *)d_vert, nPix, vcOffsets);
+        hipLaunchKernelGGL(valid_scan_kernel, dim3(1), dim3(1024), 0, stV, vcOffsets, nVcBlocks, d_nValid);
+        hipLaunchKernelGGL(valid_write_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, stV, (const float4 *)d_vert, nPix, vcOffsets, validIdx);
         DARTK_HIP(hipGetLastError());
     }
+    const FusedObs2ModArgs fa = {(const float4 *)d_vert, (const float4 *)d_norm, validIdx, d_nValid, o->distThreshold, o->normThreshold,
+                                 o->planeOffset, o->planeNormal[0], o->planeNormal[1], o->planeNormal[2], o->huberDelta, slabsA, cntA};
+    TraceArgs ta = {};
+    size_t ldsU = ldsA;
+    if (unionAB) {
+        rc = gn_raycast_reserve(ray_trace_floats(o->predWidth, o->predHeight, m.nSdfs));
+        if (rc) return rc;
+        // the tasks that survive the tile rectangles are known on the device only: a fixed number of workgroups walks them
+        const long long tasks = (long long)((o->predWidth + 7) / 8) * ((o->predHeight + 7) / 8) * m.nSdfs;
+        const long long want = (tasks + NE_BLOCK / 64 - 1) / (NE_BLOCK / 64);
+        ta = TraceArgs{o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2), o->predWidth, o->predHeight,
+                       (float2 *)ws->rayBuf, (int)(want < 2048 ? want : 2048)};
+        if (ldsU < sizeof(int) * kRectInts) ldsU = sizeof(int) * kRectInts;
+    }
     for (int it = 0; it < o->numIterations; ++it) {
-        if (fork && it > 0) {       // the pose of this iteration is final on `st` (previous solve)
+        if (sideA && it > 0) {      // the pose of this iteration is final on `st` (previous solve)
             DARTK_HIP(hipEventRecord(ws->evFork, st));
             DARTK_HIP(hipStreamWaitEvent(stA, ws->evFork, 0));
+        }
+#define DARTK_LAUNCH_FUSED(PPT_)                                                                                \
+    do {                                                                                                        \
+        if (unionAB) {                                                                                          \
+            auto kfn = trace_and_obs2mod_kernel<PPT_>;                                                          \
+            if (ldsU > 64 * 1024)                                                                               \
+                DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsU)); \
+            hipLaunchKernelGGL(kfn, dim3(ta.nTraceWgs + nBlocksA), dim3(NE_BLOCK), ldsU, st, ta, fa, m);        \
+        } else {                                                                                                \
+            auto kfn = fused_obs2mod_kernel<PPT_>;                                                              \
+            if (ldsA > 64 * 1024)                                                                               \
+                DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA)); \
+            hipLaunchKernelGGL(kfn, dim3(nBlocksA), dim3(NE_BLOCK), ldsA, stA, fa, m);                          \
+        }                                                                                                       \
+    } while (0)
+        if (unionAB) {
+            ProfScope ps(DARTK_PROF_RAYCAST, st);
+            if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_FUSED(3);
+            else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_FUSED(6);
+            else DARTK_LAUNCH_FUSED(20);
+            DARTK_HIP(hipGetLastError());
         }
         if (useB) {
             rc = gn_launch_raycast_ne_mod2obs(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2),
                                               o->predWidth, o->predHeight, 0, m, d_prediction, d_T_gc, slabsB, nBlocksB, cntB, stB,
-                                              (fork && it == 0) ? ws->evObs : nullptr);
+                                              (fork && it == 0) ? ws->evObs : nullptr, unionAB);
             if (rc) return rc;
         }
-        if (useA) {
+        if (useA && !unionAB) {
             ProfScope ps(DARTK_PROF_FUSED_OBS2MOD, stA);
-#define DARTK_LAUNCH_FUSED(PPT_)                                                                                \
-    do {                                                                                                        \
-        auto kfn = fused_obs2mod_kernel<PPT_>;                                                                  \
-        if (ldsA > 64 * 1024)                                                                                   \
-            DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA)); \
-        hipLaunchKernelGGL(kfn, dim3(nBlocksA), dim3(NE_BLOCK), ldsA, stA, (const float4 *)d_vert, (const float4 *)d_norm, \
-                           validIdx, d_nValid, m, o->distThreshold, o->normThreshold, o->planeOffset, o->planeNormal[0],      \
-                           o->planeNormal[1], o->planeNormal[2], o->huberDelta, slabsA, cntA);                  \
-    } while (0)
             if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_FUSED(3);
             else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_FUSED(6);
             else DARTK_LAUNCH_FUSED(20);
-#undef DARTK_LAUNCH_FUSED
             DARTK_HIP(hipGetLastError());
         }
+#undef DARTK_LAUNCH_FUSED
         if (useC) {
             ProfScope ps(DARTK_PROF_NE_SELF, stA);
             rc = gn_launch_ne_self(d_cloud, nCloud, m, d_potential, slabsC, nBlocksC, stA);
             if (rc) return rc;
         }
-        if (fork) {
+        if (sideA) {
             DARTK_HIP(hipEventRecord(ws->evJoin, stA));
             DARTK_HIP(hipStreamWaitEvent(st, ws->evJoin, 0));
         }

@@ -57,7 +57,7 @@ int gn_launch_cull(float *d_pred, int pw, int ph, const float *d_obs, int ow, in
 int gn_obs_sdf_build(const float *d_vert, int width, int height, Model *mod, float focalLength, hipStream_t st);
 int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                                  float *d_prediction, const float *d_T_gc, float *slabs, int nBlocks, int *d_num, hipStream_t st,
-                                 hipEvent_t beforeNe = nullptr);
+                                 hipEvent_t beforeNe = nullptr, bool traceDone = false /* the caller has launched the trace on st */);
 int gn_launch_ne_mod2obs(const float *d_pred, int width, int height, const ModelView &m, const float *d_T_gc,
                          float *slabs, int nBlocks, int *d_num, hipStream_t st);
 int gn_launch_ne_self(const float *d_sites, int nSites, const ModelView &m, const int *d_pot, float *slabs, int nBlocks,

@@ -152,11 +152,18 @@ int launch_reduce_slabs_gated(const float *slabs, int nBlocks, int S, float *res
     return DARTK_OK;
 }
 
-__global__ void __launch_bounds__(64) fk_kernel(ModelView m, int mode) {
+// The pose travels in the kernel ARGUMENTS (copied by the launch itself): no staging buffer whose reuse would need the host
+// to wait for the stream, no host->device copy packets; dartk_model_set_pose is one asynchronous launch.
+struct PoseArgs { int hasT, nJ; float T_mc[12]; float joints[DARTK_MAX_JOINTS]; };
+__global__ void __launch_bounds__(64) fk_kernel(ModelView m, int mode, PoseArgs p) {
     __shared__ float sT[12 * (DARTK_MAX_JOINTS + 1)];
+    if (p.hasT && threadIdx.x < 12) m.T_mc[threadIdx.x] = p.T_mc[threadIdx.x];
+    if ((int)threadIdx.x < p.nJ) m.joints[threadIdx.x] = p.joints[threadIdx.x];      // lane j writes joint j and is the lane fk_wave reads it with
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (mode == 0 && threadIdx.x == 0) {
-        float inv[12];
-        se3_invert(m.T_mc, inv);
+        float T[12], inv[12];
+        for (int i = 0; i < 12; ++i) T[i] = p.hasT ? p.T_mc[i] : m.T_mc[i];
+        se3_invert(T, inv);
         for (int i = 0; i < 12; ++i) m.T_cm[i] = inv[i];
     }
     fk_wave(m, mode, sT);
@@ -463,18 +470,16 @@ int dartk_model_destroy(dartk_model_t h) {
 static int upload_pose_and_fk(Model *m, const float *h_T_mc, const float *h_joints, int mode, void *stream) {
     hipStream_t st = as_stream(stream);
     const int nJ = m->v.nJoints;
-    // pinned staging is reused: wait for any previous async copy from it before overwriting
-    DARTK_HIP(hipStreamSynchronize(st));
-    if (h_T_mc) {
-        memcpy(m->h_pin, h_T_mc, 12 * sizeof(float));
-        DARTK_HIP(hipMemcpyAsync(m->v.T_mc, m->h_pin, 12 * sizeof(float), hipMemcpyHostToDevice, st));
-    }
+    PoseArgs p;
+    memset(&p, 0, sizeof(p));
+    if (h_T_mc) { p.hasT = 1; memcpy(p.T_mc, h_T_mc, 12 * sizeof(float)); }
     if (nJ > 0) {
         DARTK_REQUIRE(h_joints != nullptr, "joint array required for an articulated model");
-        memcpy(m->h_pin + 12, h_joints, nJ * sizeof(float));
-        DARTK_HIP(hipMemcpyAsync(m->v.joints, m->h_pin + 12, nJ * sizeof(float), hipMemcpyHostToDevice, st));
+        DARTK_REQUIRE(nJ <= DARTK_MAX_JOINTS, "%d joints exceed DARTK_MAX_JOINTS", nJ);
+        p.nJ = nJ;
+        memcpy(p.joints, h_joints, nJ * sizeof(float));
     }
-    hipLaunchKernelGGL(fk_kernel, dim3(1), dim3(64), 0, st, m->v, mode);
+    hipLaunchKernelGGL(fk_kernel, dim3(1), dim3(64), 0, st, m->v, mode, p);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
