@@ -44,51 +44,39 @@ void prof_pop(int idx, hipStream_t st) { (void)hipEventRecord(g_prof[idx].b, st)
 // are compacted once per call into an index list (deterministic: pixel order is kept), and every iteration's fused
 // kernel runs one full tile of real work per workgroup instead of striding over a mostly empty image.
 static constexpr int VC_BLOCK = 256;
+// zero2 (optional): two counters the iteration's kernels expect at zero (this is the first kernel of the call on its stream)
 __global__ void __launch_bounds__(VC_BLOCK)
-valid_count_kernel(const float4 *__restrict__ vert, int nPix, int *__restrict__ blockCounts) {
+valid_count_kernel(const float4 *__restrict__ vert, int nPix, int *__restrict__ blockCounts, int *__restrict__ zero2) {
     __shared__ int wc[VC_BLOCK / 64];
     const int index = blockIdx.x * VC_BLOCK + threadIdx.x;
     const bool v = index < nPix && vert[index].w > 0;
     const unsigned long long mask = __ballot(v);
     if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(mask);
     __syncthreads();
-    if (threadIdx.x == 0) blockCounts[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
-}
-// exclusive scan of the block counts in place (one workgroup, serial carry over chunks of 1024); total -> *nValid
-__global__ void __launch_bounds__(1024)
-valid_scan_kernel(int *__restrict__ blockCounts, int nBlocks, int *__restrict__ nValid) {
-    __shared__ int buf[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nBlocks; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < nBlocks ? blockCounts[i] : 0;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const int t = (int)threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += t;
-            __syncthreads();
-        }
-        const int incl = buf[threadIdx.x];
-        const int c = carry;
-        if (i < nBlocks) blockCounts[i] = c + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = c + incl;
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        blockCounts[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+        if (zero2 && blockIdx.x == 0) { zero2[0] = 0; zero2[1] = 0; }
     }
-    if (threadIdx.x == 0) *nValid = carry;
 }
+// every workgroup sums the counts of the workgroups before it (a few KB, integer sums: order-free) instead of waiting for a scan
+// kernel of its own -- one launch less at the head of every call; the last workgroup leaves the total in *nValid
 __global__ void __launch_bounds__(VC_BLOCK)
-valid_write_kernel(const float4 *__restrict__ vert, int nPix, const int *__restrict__ blockOffsets, int *__restrict__ validIdx) {
+valid_write_kernel(const float4 *__restrict__ vert, int nPix, const int *__restrict__ blockCounts, int *__restrict__ validIdx,
+                   int *__restrict__ nValid) {
     __shared__ int wc[VC_BLOCK / 64];
+    __shared__ int ws[VC_BLOCK / 64];
+    int before = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += VC_BLOCK) before += blockCounts[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = before;
     const int index = blockIdx.x * VC_BLOCK + threadIdx.x;
     const bool v = index < nPix && vert[index].w > 0;
     int total;
-    const int slot = compact_slot<VC_BLOCK>(v, wc, total);
-    if (v) validIdx[blockOffsets[blockIdx.x] + slot] = index;
+    const int slot = compact_slot<VC_BLOCK>(v, wc, total);      // (synchronises the workgroup)
+    const int off = ws[0] + ws[1] + ws[2] + ws[3];
+    if (v) validIdx[off + slot] = index;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *nValid = off + total;
 }
 
 // One tile of NE_BLOCK valid pixels per workgroup; workgroups past the end of the list exit (their slab is never read).
@@ -765,7 +753,10 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
 #endif
     const bool sideA = fork && (!unionAB || useC);
     hipStream_t stB = st, stA = sideA ? ws->auxStream : st, stO = fork ? ws->auxStream2 : st;
-    DARTK_HIP(hipMemsetAsync(ws->counters, 0, 2 * sizeof(int), st));      // before the fork; later iterations: zeroed by the solve kernel
+    // the two counters start at zero (later iterations: zeroed by the solve kernel): with the shared launch the call's first kernel
+    // on `st`, the valid-pixel count, does it; else a memset before the fork
+    const bool zeroInCount = unionAB;
+    if (!zeroInCount) DARTK_HIP(hipMemsetAsync(ws->counters, 0, 2 * sizeof(int), st));
     // an error return after a fork must leave the caller's stream ordered after the side streams: they write the slab, index
     // and system buffers of this workspace, which the next call on `st` reuses
     struct JoinGuard {
@@ -785,10 +776,9 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     if (useB) {     // the obs SDF is first read by iteration 0's mod->obs kernel: built on a third stream beside the ray-cast
         {
             ProfScope ps(DARTK_PROF_OBS_SDF, stO);
-            rc = gn_obs_sdf_build(d_vert, width, height, mod, o->focalLength, stO);
+            rc = gn_obs_sdf_build(d_vert, width, height, mod, o->focalLength, stO, d_T_gc);     // also freezes T_gc = T_mc (optimizer.cpp:446-448)
         }
         if (rc) return rc;
-        DARTK_HIP(hipMemcpyAsync(d_T_gc, m.T_mc, 12 * sizeof(float), hipMemcpyDeviceToDevice, stO));
         if (fork) DARTK_HIP(hipEventRecord(ws->evObs, stO));
     }
     const size_t ldsA = sizeof(float) * (24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8);
@@ -800,9 +790,9 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     hipStream_t stV = unionAB ? st : stA;        // the valid-pixel list is read by the obs->mod tiles, wherever they run
     if (useA && o->numIterations > 0) {
         ProfScope ps(DARTK_PROF_OTHER, stV);
-        hipLaunchKernelGGL(valid_count_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, stV, (const float4 *)d_vert, nPix, vcOffsets);
-        hipLaunchKernelGGL(valid_scan_kernel, dim3(1), dim3(1024), 0, stV, vcOffsets, nVcBlocks, d_nValid);
-        hipLaunchKernelGGL(valid_write_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, stV, (const float4 *)d_vert, nPix, vcOffsets, validIdx);
+        hipLaunchKernelGGL(valid_count_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, stV, (const float4 *)d_vert, nPix, vcOffsets,
+                           zeroInCount ? ws->counters : nullptr);
+        hipLaunchKernelGGL(valid_write_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, stV, (const float4 *)d_vert, nPix, vcOffsets, validIdx, d_nValid);
         DARTK_HIP(hipGetLastError());
     }
     const FusedObs2ModArgs fa = {(const float4 *)d_vert, (const float4 *)d_norm, validIdx, d_nValid, o->distThreshold, o->normThreshold,

@@ -54,7 +54,8 @@ int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float p
 int gn_launch_raycast(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                       float *d_prediction, hipStream_t st);
 int gn_launch_cull(float *d_pred, int pw, int ph, const float *d_obs, int ow, int oh, hipStream_t st);
-int gn_obs_sdf_build(const float *d_vert, int width, int height, Model *mod, float focalLength, hipStream_t st);
+int gn_obs_sdf_build(const float *d_vert, int width, int height, Model *mod, float focalLength, hipStream_t st,
+                     float *d_T_gc_out = nullptr /* optional: receives the camera->model transform the splat was made with */);
 int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                                  float *d_prediction, const float *d_T_gc, float *slabs, int nBlocks, int *d_num, hipStream_t st,
                                  hipEvent_t beforeNe = nullptr, bool traceDone = false /* the caller has launched the trace on st */);

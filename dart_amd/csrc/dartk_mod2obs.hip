@@ -190,12 +190,16 @@ __global__ void cull_unobservable_kernel(float4 *__restrict__ pred, int pw, int 
 }
 
 // gpu_splatObsSdf, modToObs.cu:403-441
-__global__ void splat_obs_sdf_kernel(const float4 *__restrict__ vert, int width, int height, ModelView m_in, float focalLength, FrameBatch fb) {
+// dst: where the splat goes ([frames][voxels]; the distance transform that follows ends in the model's obsData).
+// T_gc_out (optional, single frame): receives the camera->model transform the splat was made with (the observation SDF's frame).
+__global__ void splat_obs_sdf_kernel(const float4 *__restrict__ vert, int width, int height, ModelView m_in, float focalLength, FrameBatch fb,
+                                     float *__restrict__ dst, float *__restrict__ T_gc_out) {
     ModelView m = m_in;
     select_frame(m, blockIdx.y);                    // frame of a batch (0 otherwise)
     vert += (size_t)blockIdx.y * fb.vert;
     const int nVox = m.obs.dimx * m.obs.dimy * m.obs.dimz;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (T_gc_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 12) T_gc_out[threadIdx.x] = m.T_mc[threadIdx.x];
     if (i >= nVox) return;
     const int x = i % m.obs.dimx, y = (i / m.obs.dimx) % m.obs.dimy, z = i / (m.obs.dimx * m.obs.dimy);
     const float *__restrict__ T_cm = m.T_cm;
@@ -211,7 +215,7 @@ __global__ void splat_obs_sdf_kernel(const float4 *__restrict__ vert, int width,
         else if (o.z < c.z) val = 0.0f;
         else val = 1000.0f;
     }
-    m.obsData[i] = val;
+    dst[(size_t)blockIdx.y * nVox + i] = val;
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -606,17 +610,17 @@ int gn_launch_cull(float *d_pred, int pw, int ph, const float *d_obs, int ow, in
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
-int gn_obs_sdf_build(const float *d_vert, int width, int height, Model *mod, float focalLength, hipStream_t st) {
+int gn_obs_sdf_build(const float *d_vert, int width, int height, Model *mod, float focalLength, hipStream_t st, float *d_T_gc_out) {
     const ModelView &m = mod->v;
     const int n = (int)mod->obsVoxels;
     const FrameBatch fb = cur_batch();              // a batch: the frames' observation SDFs lie obsStride (= n) floats apart
     DARTK_REQUIRE(fb.n == 1 || m.obsStride == n, "batched observation SDFs must be contiguous");
-    hipLaunchKernelGGL(splat_obs_sdf_kernel, dim3((n + 255) / 256, fb.n), dim3(256), 0, st, (const float4 *)d_vert, width, height, m, focalLength, fb);
+    // the splat goes to the scratch volume and the transform's three passes (scratch -> obsData -> scratch -> obsData) leave the
+    // result in place: no copy back (the reference copies, optimizer.cpp:215)
+    hipLaunchKernelGGL(splat_obs_sdf_kernel, dim3((n + 255) / 256, fb.n), dim3(256), 0, st, (const float4 *)d_vert, width, height, m, focalLength, fb,
+                       mod->dtTmp, d_T_gc_out);
     DARTK_HIP(hipGetLastError());
-    int rc = launch_distance_transform_3d(m.obsData, mod->dtTmp, m.obs.dimx, m.obs.dimy, m.obs.dimz, 1, st, fb.n);
-    if (rc) return rc;
-    DARTK_HIP(hipMemcpyAsync(m.obsData, mod->dtTmp, sizeof(float) * (size_t)n * fb.n, hipMemcpyDeviceToDevice, st));  // optimizer.cpp:215
-    return DARTK_OK;
+    return launch_distance_transform_3d(mod->dtTmp, m.obsData, m.obs.dimx, m.obs.dimy, m.obs.dimz, 1, st, fb.n);
 }
 
 // gpu_errorModToObs, modToObs.cu:649-680 (prediction used in camera coordinates, as the reference does)
