@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdartk.so")
+# DARTK_LIB: a diagnostic variant of the library (tools/build_variant.py); the product is libdartk.so
+LIB_PATH = os.environ.get("DARTK_LIB") or os.path.join(_HERE, "libdartk.so")
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int32)

@@ -30,6 +30,10 @@ struct BatchScope {         // sets the current batch for a scope
     ~BatchScope() { cur_batch() = saved; }
 };
 
+// ring of (pinned host, device) argument slots, see dartk_model.hip
+struct ArgSlot { void *d; void *h; int idx, dev; };
+int arg_ring_acquire(size_t bytes, ArgSlot *out);
+int arg_ring_release(const ArgSlot &s, hipStream_t st);
 int ensure_partials(Workspace *w, size_t floats);
 void registry_add(Model *m);           // dartk_tables.hip: live model handles by their device arrays
 void registry_remove(Model *m);

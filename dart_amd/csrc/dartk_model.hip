@@ -57,6 +57,39 @@ int get_workspace(Workspace **out) {
     return DARTK_OK;
 }
 
+// Argument blocks that are too large to pass by value travel through a small ring of (pinned host, device) slot pairs: a call
+// fills the next slot, uploads it asynchronously and marks it released once its last consumer is enqueued. The host only ever
+// waits when the ring has wrapped around onto a slot whose consumer has not finished -- eight calls ahead of the device.
+static constexpr int kArgSlots = 8;
+static constexpr size_t kArgSlotBytes = 4096;
+struct ArgRing { char *d; char *h; hipEvent_t ev[kArgSlots]; bool used[kArgSlots]; int next; bool ready; };
+static ArgRing g_argRing[16];
+int arg_ring_acquire(size_t bytes, ArgSlot *out) {
+    int dev = 0;
+    DARTK_HIP(hipGetDevice(&dev));
+    DARTK_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+    DARTK_REQUIRE(bytes <= kArgSlotBytes, "argument block of %zu bytes exceeds the %zu-byte slots", bytes, kArgSlotBytes);
+    ArgRing &r = g_argRing[dev];
+    if (!r.ready) {
+        DARTK_HIP(hipMalloc((void **)&r.d, kArgSlots * kArgSlotBytes));
+        DARTK_HIP(hipHostMalloc((void **)&r.h, kArgSlots * kArgSlotBytes, hipHostMallocDefault));
+        for (int i = 0; i < kArgSlots; ++i) { DARTK_HIP(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming)); r.used[i] = false; }
+        r.next = 0; r.ready = true;
+    }
+    const int i = r.next;
+    r.next = (r.next + 1) % kArgSlots;
+    if (r.used[i]) DARTK_HIP(hipEventSynchronize(r.ev[i]));
+    r.used[i] = false;
+    out->d = r.d + (size_t)i * kArgSlotBytes; out->h = r.h + (size_t)i * kArgSlotBytes; out->idx = i; out->dev = dev;
+    return DARTK_OK;
+}
+int arg_ring_release(const ArgSlot &s, hipStream_t st) {
+    ArgRing &r = g_argRing[s.dev];
+    DARTK_HIP(hipEventRecord(r.ev[s.idx], st));
+    r.used[s.idx] = true;
+    return DARTK_OK;
+}
+
 static void *g_multiArgs[16] = {nullptr};
 static size_t g_multiArgsBytes[16] = {0};
 int get_multi_args_buffer(void **d_ptr, size_t bytes) {

@@ -444,7 +444,11 @@ int dartk_assoc_multi(const float *d_vert, const float *d_norm, int width, int h
     Workspace *ws;
     int rc = get_workspace(&ws);
     if (rc) return rc;
-    static thread_local MultiArgs hargs;
+    // the argument block goes through the ring of pinned slots: no host wait per call (the reference's wrapper does not block either)
+    ArgSlot slot;
+    rc = arg_ring_acquire(sizeof(MultiArgs), &slot);
+    if (rc) return rc;
+    MultiArgs &hargs = *reinterpret_cast<MultiArgs *>(slot.h);
     hargs.nModels = nModels;
     for (int i = 0; i < nModels; ++i) {
         Model *mod = reinterpret_cast<Model *>(models[i]);
@@ -455,11 +459,8 @@ int dartk_assoc_multi(const float *d_vert, const float *d_norm, int width, int h
         for (int k = 0; k < 3; ++k) hargs.pn[i][k] = h_planeNormals3[3 * i + k];
         hargs.pts[i] = h_pts_table[i];
     }
-    MultiArgs *d_args = nullptr;
-    rc = get_multi_args_buffer((void **)&d_args, sizeof(MultiArgs));
-    if (rc) return rc;
+    MultiArgs *d_args = reinterpret_cast<MultiArgs *>(slot.d);
     DARTK_HIP(hipMemcpyAsync(d_args, &hargs, sizeof(MultiArgs), hipMemcpyHostToDevice, st));
-    DARTK_HIP(hipStreamSynchronize(st));   // hargs is reused by the next call
     DARTK_HIP(hipMemsetAsync(d_last, 0, nModels * sizeof(int), st));
     const int nPix = width * height;
     const dim3 grid((nPix + 255) / 256), block(256);
@@ -468,7 +469,7 @@ int dartk_assoc_multi(const float *d_vert, const float *d_norm, int width, int h
     else
         hipLaunchKernelGGL(assoc_multi_kernel<false>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, nullptr, nullptr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0});
     DARTK_HIP(hipGetLastError());
-    return DARTK_OK;
+    return arg_ring_release(slot, st);
 }
 
 int dartk_ne_obs2mod(int dims, const float *d_vert, int width, int height, dartk_model_t h, float huberDelta,
