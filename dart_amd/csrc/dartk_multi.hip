@@ -478,9 +478,18 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     h.iterInfo = d_iterInfo; h.firstSystem = d_firstSystem;
     h.priors = d_priors; h.nPriors = nPriors;
     h.fb = fb; h.redStride = batch ? redTotal : 0; h.infoStride = batch ? (size_t)o->numIterations * n * 8 : 0; h.T_mcs = d_T_mcs;
-    DARTK_HIP(hipMemcpyAsync(d_args, &h, sizeof(h), hipMemcpyHostToDevice, st));
-    if (!tables.empty()) DARTK_HIP(hipMemcpyAsync(fl, tables.data(), sizeof(float) * tables.size(), hipMemcpyHostToDevice, st));
-    DARTK_HIP(hipStreamSynchronize(st));        // h and tables are host temporaries
+    {   // argument block and tables leave through a pinned slot: the call does not wait for the stream
+        ArgSlot slot;
+        rc = arg_ring_acquire(sizeof(h) + sizeof(float) * tables.size(), &slot);
+        if (rc) return rc;
+        memcpy(slot.h, &h, sizeof(h));
+        float *hTab = reinterpret_cast<float *>((char *)slot.h + sizeof(h));
+        if (!tables.empty()) memcpy(hTab, tables.data(), sizeof(float) * tables.size());
+        DARTK_HIP(hipMemcpyAsync(d_args, slot.h, sizeof(h), hipMemcpyHostToDevice, st));
+        if (!tables.empty()) DARTK_HIP(hipMemcpyAsync(fl, hTab, sizeof(float) * tables.size(), hipMemcpyHostToDevice, st));
+        rc = arg_ring_release(slot, st);
+        if (rc) return rc;
+    }
 
     const int ldU = (D + 1) | 1;
     const size_t ldsSolve = sizeof(float) * ((size_t)2 * D * ldU + 2 * D + 64 + 12 * (size_t)maxFrames + 8);

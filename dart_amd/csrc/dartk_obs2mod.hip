@@ -369,7 +369,10 @@ static int launch_ne_obs2mod_noalloc(int dims, const float *d_vert, Model *mod, 
 // (the ModelViews point at pose arrays that are updated in place), then one launch per iteration
 int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr, const float *planeOffset, const float *pn3,
                            dartk_da_point *const *pts, void **d_args_out, hipStream_t st) {
-    static thread_local MultiArgs hargs;
+    ArgSlot slot;           // pinned staging: the upload needs no host wait (the slot is released as soon as the copy is enqueued)
+    int rc = arg_ring_acquire(sizeof(MultiArgs), &slot);
+    if (rc) return rc;
+    MultiArgs &hargs = *reinterpret_cast<MultiArgs *>(slot.h);
     hargs.nModels = nModels;
     for (int i = 0; i < nModels; ++i) {
         hargs.m[i] = mods[i]->v;
@@ -379,10 +382,11 @@ int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr
         hargs.pts[i] = pts[i];
     }
     MultiArgs *d_args = nullptr;
-    int rc = get_multi_args_buffer((void **)&d_args, sizeof(MultiArgs));
+    rc = get_multi_args_buffer((void **)&d_args, sizeof(MultiArgs));
     if (rc) return rc;
     DARTK_HIP(hipMemcpyAsync(d_args, &hargs, sizeof(MultiArgs), hipMemcpyHostToDevice, st));
-    DARTK_HIP(hipStreamSynchronize(st));   // hargs is reused by the next call
+    rc = arg_ring_release(slot, st);
+    if (rc) return rc;
     *d_args_out = d_args;
     return DARTK_OK;
 }
