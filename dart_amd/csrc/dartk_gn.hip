@@ -45,9 +45,12 @@ void prof_pop(int idx, hipStream_t st) { (void)hipEventRecord(g_prof[idx].b, st)
 // kernel runs one full tile of real work per workgroup instead of striding over a mostly empty image.
 static constexpr int VC_BLOCK = 256;
 // zero2 (optional): two counters the iteration's kernels expect at zero (this is the first kernel of the call on its stream)
+// (both kernels: grid.y = frame of a batch; the frames' maps, counts, lists and totals lie nPix / gridDim.x / nPix / 1 apart)
 __global__ void __launch_bounds__(VC_BLOCK)
 valid_count_kernel(const float4 *__restrict__ vert, int nPix, int *__restrict__ blockCounts, int *__restrict__ zero2) {
     __shared__ int wc[VC_BLOCK / 64];
+    vert += (size_t)blockIdx.y * nPix;
+    blockCounts += (size_t)blockIdx.y * gridDim.x;
     const int index = blockIdx.x * VC_BLOCK + threadIdx.x;
     const bool v = index < nPix && vert[index].w > 0;
     const unsigned long long mask = __ballot(v);
@@ -55,7 +58,7 @@ valid_count_kernel(const float4 *__restrict__ vert, int nPix, int *__restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) {
         blockCounts[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
-        if (zero2 && blockIdx.x == 0) { zero2[0] = 0; zero2[1] = 0; }
+        if (zero2 && blockIdx.x == 0 && blockIdx.y == 0) { zero2[0] = 0; zero2[1] = 0; }
     }
 }
 // every workgroup sums the counts of the workgroups before it (a few KB, integer sums: order-free) instead of waiting for a scan
@@ -65,6 +68,10 @@ valid_write_kernel(const float4 *__restrict__ vert, int nPix, const int *__restr
                    int *__restrict__ nValid) {
     __shared__ int wc[VC_BLOCK / 64];
     __shared__ int ws[VC_BLOCK / 64];
+    vert += (size_t)blockIdx.y * nPix;
+    blockCounts += (size_t)blockIdx.y * gridDim.x;
+    validIdx += (size_t)blockIdx.y * nPix;
+    nValid += blockIdx.y;
     int before = 0;
     for (int b = threadIdx.x; b < (int)blockIdx.x; b += VC_BLOCK) before += blockCounts[b];
 #pragma unroll
@@ -77,6 +84,15 @@ valid_write_kernel(const float4 *__restrict__ vert, int nPix, const int *__restr
     const int off = ws[0] + ws[1] + ws[2] + ws[3];
     if (v) validIdx[off + slot] = index;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *nValid = off + total;
+}
+
+// d_work: [frames][ceil(nPix/256)] ints of scratch; d_validIdx: [frames][nPix]; d_nValid: [frames]
+int gn_valid_pixels(const float *d_vert, int nPix, int nFrames, int *d_work, int *d_validIdx, int *d_nValid, hipStream_t st) {
+    const int nb = (nPix + VC_BLOCK - 1) / VC_BLOCK;
+    hipLaunchKernelGGL(valid_count_kernel, dim3(nb, nFrames), dim3(VC_BLOCK), 0, st, (const float4 *)d_vert, nPix, d_work, (int *)nullptr);
+    hipLaunchKernelGGL(valid_write_kernel, dim3(nb, nFrames), dim3(VC_BLOCK), 0, st, (const float4 *)d_vert, nPix, d_work, d_validIdx, d_nValid);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
 }
 
 // One tile of NE_BLOCK valid pixels per workgroup; workgroups past the end of the list exit (their slab is never read).

@@ -58,6 +58,9 @@ int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float p
 int gn_launch_raycast(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                       float *d_prediction, hipStream_t st);
 int gn_launch_cull(float *d_pred, int pw, int ph, const float *d_obs, int ow, int oh, hipStream_t st);
+// per frame the indices of the pixels with a valid vertex (w > 0), in pixel order: the observation is fixed for a whole
+// optimisation call, so the association kernels of its iterations walk this list instead of the map
+int gn_valid_pixels(const float *d_vert, int nPix, int nFrames, int *d_work, int *d_validIdx, int *d_nValid, hipStream_t st);
 int gn_obs_sdf_build(const float *d_vert, int width, int height, Model *mod, float focalLength, hipStream_t st,
                      float *d_T_gc_out = nullptr /* optional: receives the camera->model transform the splat was made with */);
 int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
@@ -74,7 +77,8 @@ int gn_launch_ne_obs2mod_dev(int red, int fullDims, int redDims, const float *d_
                              const int *d_map, float *d_result, hipStream_t st);
 int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr, const float *planeOffset, const float *pn3,
                            dartk_da_point *const *pts, void **d_args_out, hipStream_t st);
-int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void *d_args, int *d_last, hipStream_t st);
+int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void *d_args, int *d_last, hipStream_t st,
+                          const int *d_validIdx = nullptr, const int *d_nValid = nullptr);
 int gn_ne_mod2obs_any(int red, int fullDims, int redDims, const float *d_pred, int width, int height, Model *mod,
                       const float *d_T_gc, const float *d_A, const int *d_map, float *d_result, int *d_num, hipStream_t st);
 int gn_ne_self_any(int red, const float *d_sites, int nSites, int fullDims, int redDims, Model *mod, const float *d_A,

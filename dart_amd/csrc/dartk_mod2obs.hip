@@ -138,7 +138,8 @@ raycast_replay_multi_kernel(float flx, float fly, float ppx, float ppy, int widt
     if (valid) {
         const int ox = x * ow / width, oy = y * oh / height;
         const int oi = ox + oy * ow;
-        if (obs[oi].w <= 0 || obs[oi + 1].w <= 0 || obs[oi + ow].w <= 0 || obs[oi + ow + 1].w <= 0) pr.z = 0;
+        // cullUnobservable only ever clears z: pixels without a hit (most of the map) need not look at the observation
+        if (pr.z != 0 && (obs[oi].w <= 0 || obs[oi + 1].w <= 0 || obs[oi + ow].w <= 0 || obs[oi + ow + 1].w <= 0)) pr.z = 0;
         prediction[index] = pr;
     }
 }

@@ -511,6 +511,20 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         rc = gn_assoc_multi_prepare(n, mods, thr, po, pn, ptsList, &d_assocArgs, st);
         if (rc) return rc;
     }
+    // The observation is fixed for the call: its valid pixels (a few per cent of a 1280x720 map around a hand) are listed once
+    // per frame, and every iteration's association walks the lists instead of reading every vertex of every frame again.
+    int *d_validIdx = nullptr, *d_nValid = nullptr;
+    if (useA && o->numIterations > 0) {
+        const int nb = (nPix + 255) / 256;
+        rc = ensure_valid_idx(ws, (size_t)nFrames * ((size_t)nPix + nb + 1));
+        if (rc) return rc;
+        d_validIdx = ws->validIdx;
+        int *d_work = d_validIdx + (size_t)nFrames * nPix;
+        d_nValid = d_work + (size_t)nFrames * nb;
+        ProfScope ps(DARTK_PROF_OTHER, st);
+        rc = gn_valid_pixels(d_vert, nPix, nFrames, d_work, d_validIdx, d_nValid, st);
+        if (rc) return rc;
+    }
     // generateObsSdf per model with its start pose (optimizer.cpp:574-580); the full-pose mod->obs wrapper works in that frame
     if (useB) {
         for (int m = 0; m < n; ++m) {
@@ -576,7 +590,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         if (useA) {
             {
                 ProfScope ps(DARTK_PROF_OTHER, stA);
-                rc = gn_assoc_multi_launch(d_vert, nPix, n, d_assocArgs, d_countA, stA);
+                rc = gn_assoc_multi_launch(d_vert, nPix, n, d_assocArgs, d_countA, stA, d_validIdx, d_nValid);
                 if (rc) return rc;
             }
             for (int m = 0; m < n; ++m) {

@@ -74,11 +74,17 @@ struct MultiArgs {
 template <bool DBG>
 __global__ void __launch_bounds__(256)
 assoc_multi_kernel(const float4 *__restrict__ vert, int nPix, const MultiArgs *__restrict__ args,
-                   int *__restrict__ lastElement, int *__restrict__ dbgDA, float *__restrict__ dbgErr, FrameBatch fb) {
-    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+                   int *__restrict__ lastElement, int *__restrict__ dbgDA, float *__restrict__ dbgErr, FrameBatch fb,
+                   const int *__restrict__ validIdx, const int *__restrict__ nValid) {
+    int index = blockIdx.x * blockDim.x + threadIdx.x;
     const int frame = blockIdx.y;                    // frame of a batch (0 otherwise)
     vert += (size_t)frame * fb.vert;
     lastElement += (size_t)frame * fb.counts;
+    if (validIdx) {         // walk the frame's list of valid pixels (gn_valid_pixels) instead of the map
+        const int n = nValid[frame];
+        if ((int)(blockIdx.x * blockDim.x) >= n) return;
+        index = index < n ? validIdx[(size_t)frame * nPix + index] : nPix;
+    }
     int aModel = -1, aGrid = -1;
     float sdfError = 1e20f;
     if (index < nPix) {
@@ -390,11 +396,12 @@ int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr
     *d_args_out = d_args;
     return DARTK_OK;
 }
-int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void *d_args, int *d_last, hipStream_t st) {
+int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void *d_args, int *d_last, hipStream_t st,
+                          const int *d_validIdx, const int *d_nValid) {
     const FrameBatch fb = cur_batch();
     DARTK_HIP(hipMemsetAsync(d_last, 0, (fb.n > 1 ? (size_t)fb.n * fb.counts : (size_t)nModels) * sizeof(int), st));
     hipLaunchKernelGGL(assoc_multi_kernel<false>, dim3((nPix + 255) / 256, fb.n), dim3(256), 0, st, (const float4 *)d_vert, nPix,
-                       (const MultiArgs *)d_args, d_last, nullptr, nullptr, fb);
+                       (const MultiArgs *)d_args, d_last, nullptr, nullptr, fb, d_validIdx, d_nValid);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
@@ -469,9 +476,11 @@ int dartk_assoc_multi(const float *d_vert, const float *d_norm, int width, int h
     const int nPix = width * height;
     const dim3 grid((nPix + 255) / 256), block(256);
     if (d_dbgDA || d_dbgErr)
-        hipLaunchKernelGGL(assoc_multi_kernel<true>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, d_dbgDA, d_dbgErr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0});
+        hipLaunchKernelGGL(assoc_multi_kernel<true>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, d_dbgDA, d_dbgErr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0},
+                           (const int *)nullptr, (const int *)nullptr);
     else
-        hipLaunchKernelGGL(assoc_multi_kernel<false>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, nullptr, nullptr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0});
+        hipLaunchKernelGGL(assoc_multi_kernel<false>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, nullptr, nullptr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0},
+                           (const int *)nullptr, (const int *)nullptr);
     DARTK_HIP(hipGetLastError());
     return arg_ring_release(slot, st);
 }
