@@ -7,6 +7,8 @@
 #include "dartk_kernels.h"
 #include "dartk_raycast.h"
 
+#include <cstdlib>
+
 namespace dartk {
 
 // -----------------------------------------------------------------------------------------------------
@@ -144,6 +146,55 @@ raycast_replay_multi_kernel(float flx, float fly, float ppx, float ppy, int widt
     }
 }
 
+// The same with every model's tables resident in LDS at once (dynamic LDS: per model the rectangle table [4 nSdfs + 1] and the
+// per-SDF transforms [24 nSdfs]) and each workgroup walking MANY 256-pixel chunks of its frame. What a launch of the kernel
+// above costs on a batch is not the pixels but its prologue -- per model a chain of dependent loads (SDF headers, pose,
+// rectangles, transforms) and barriers, paid by every one of the 900 workgroups of a 640x360 frame: 650 us for 64 frames.
+// Here a frame takes a few dozen workgroups and each pays the prologue once.
+__global__ void __launch_bounds__(256)
+raycast_replay_multi_rows_kernel(float flx, float fly, float ppx, float ppy, int width, int height, ReplayMultiArgs a,
+                                 const float *__restrict__ rayBuf, float4 *__restrict__ prediction, const float4 *__restrict__ obs, int ow,
+                                 int oh, FrameBatch fb) {
+    extern __shared__ float lds[];
+    const int frame = blockIdx.y;
+    rayBuf += (size_t)frame * fb.trace;
+    prediction += (size_t)frame * fb.pred;
+    obs += (size_t)frame * fb.vert;
+    const int nPix = width * height;
+    {
+        int off = 0;
+        for (int mi = 0; mi < a.n; ++mi) {
+            ModelView m = a.m[mi];
+            select_frame(m, frame);
+            const int n = m.nSdfs;
+            stage_ray_rects(m, 0.0f, flx, fly, ppx, ppy, width, height, reinterpret_cast<int *>(lds + off));
+            replay_stage_transforms(m, 0, n, lds + off + 4 * n + 1);
+            off += 28 * n + 1;
+        }
+        __syncthreads();
+    }
+    const int nChunks = (nPix + 255) / 256;
+    for (int chunk = blockIdx.x; chunk < nChunks; chunk += gridDim.x) {
+        const int index = chunk * 256 + threadIdx.x;
+        if (index >= nPix) continue;
+        const int x = index % width, y = index / width;
+        float4 pr = prediction[index];
+        pr.z = 0; pr.w = -1;                        // model 0 starts the map (x, y keep what the map held, as there)
+        int off = 0;
+        for (int mi = 0; mi < a.n; ++mi) {
+            const int n = a.m[mi].nSdfs;
+            float closestT = 10000;
+            replay_pixel(pr, closestT, x, y, n, reinterpret_cast<const int *>(lds + off), mi, 0, n, lds + off + 4 * n + 1,
+                         reinterpret_cast<const float2 *>(rayBuf + a.off[mi]), flx, fly, ppx, ppy);
+            off += 28 * n + 1;
+        }
+        const int ox = x * ow / width, oy = y * oh / height;
+        const int oi = ox + oy * ow;
+        if (pr.z != 0 && (obs[oi].w <= 0 || obs[oi + 1].w <= 0 || obs[oi + ow].w <= 0 || obs[oi + ow + 1].w <= 0)) pr.z = 0;
+        prediction[index] = pr;
+    }
+}
+
 // the trace alone (the replay is done by the consumer: ne_mod2obs_kernel<.., REPLAY = true>)
 static int launch_raycast_trace(float flx, float fly, float ppx, float ppy, int width, int height, const ModelView &m, float levelSet,
                                 Workspace *ws, hipStream_t st, size_t bufOffset = 0) {
@@ -156,7 +207,9 @@ static int launch_raycast_trace(float flx, float fly, float ppx, float ppy, int 
     DARTK_REQUIRE(m.nSdfs <= kMaxRaySdfs, "ray-cast supports at most %d SDFs per model, got %d", kMaxRaySdfs, m.nSdfs);
     // the tasks that survive the tile rectangles are known on the device only: a fixed grid walks them (4 waves per workgroup,
     // one task per wave and pass); a single frame gets enough workgroups for the whole chip, a batch shares it among its frames
-    const long long want = cur_batch().n > 1 ? 192 : 1024;
+    // (measured sweep on 64 frames, tools/time_batch_replay.sh: 24-96 per frame equal, 192 +2 %, 384 +7 %)
+    static const char *envT = getenv("DARTK_TRACE_WGS");      // diagnostic override: workgroups per frame of a batch
+    const long long want = cur_batch().n > 1 ? (envT ? atoi(envT) : 64) : 1024;
     const unsigned blocks = (unsigned)((tasks + 3) / 4 < want ? (tasks + 3) / 4 : want);
     ProfScope ps(DARTK_PROF_RAYCAST, st);
     hipLaunchKernelGGL(raycast_trace_kernel, dim3(blocks, cur_batch().n), dim3(256), 0, st, flx, fly, ppx, ppy, width, height, m,
@@ -544,9 +597,20 @@ int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float p
     a.n = nModels;
     for (int m = 0; m < nModels; ++m) { a.m[m] = mods[m]->v; a.off[m] = bufOffsets[m]; }
     const size_t nPix = (size_t)width * height;
+    size_t ldsFloats = 0;
+    for (int m = 0; m < nModels; ++m) ldsFloats += 28 * (size_t)mods[m]->v.nSdfs + 1;
     ProfScope ps2(DARTK_PROF_RAYCAST_REPLAY, st);
-    hipLaunchKernelGGL(raycast_replay_multi_kernel, dim3((unsigned)((nPix + 255) / 256), cur_batch().n), dim3(256), 0, st, flx, fly, ppx, ppy, width, height,
-                       a, (const float *)ws->rayBuf, (float4 *)d_prediction, (const float4 *)d_obs, ow, oh, cur_batch());
+    const int nChunks = (int)((nPix + 255) / 256);
+    if (cur_batch().n > 1 && ldsFloats * sizeof(float) <= 64 * 1024) {
+        // a batch: a few thousand workgroups in all, each walking many chunks of its frame with the tables staged once
+        static const char *env = getenv("DARTK_REPLAY_WGS");     // diagnostic override of the launch's workgroup budget
+        int perFrame = (env ? atoi(env) : 2048) / cur_batch().n;
+        perFrame = perFrame < 1 ? 1 : (perFrame > nChunks ? nChunks : perFrame);
+        hipLaunchKernelGGL(raycast_replay_multi_rows_kernel, dim3(perFrame, cur_batch().n), dim3(256), ldsFloats * sizeof(float), st, flx, fly,
+                           ppx, ppy, width, height, a, (const float *)ws->rayBuf, (float4 *)d_prediction, (const float4 *)d_obs, ow, oh, cur_batch());
+    } else
+        hipLaunchKernelGGL(raycast_replay_multi_kernel, dim3((unsigned)nChunks, cur_batch().n), dim3(256), 0, st, flx, fly, ppx, ppy, width, height,
+                           a, (const float *)ws->rayBuf, (float4 *)d_prediction, (const float4 *)d_obs, ow, oh, cur_batch());
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
