@@ -76,15 +76,15 @@ __global__ void __launch_bounds__(256)
 assoc_multi_kernel(const float4 *__restrict__ vert, int nPix, const MultiArgs *__restrict__ args,
                    int *__restrict__ lastElement, int *__restrict__ dbgDA, float *__restrict__ dbgErr, FrameBatch fb,
                    const int *__restrict__ validIdx, const int *__restrict__ nValid) {
-    int index = blockIdx.x * blockDim.x + threadIdx.x;
     const int frame = blockIdx.y;                    // frame of a batch (0 otherwise)
     vert += (size_t)frame * fb.vert;
     lastElement += (size_t)frame * fb.counts;
-    if (validIdx) {         // walk the frame's list of valid pixels (gn_valid_pixels) instead of the map
-        const int n = nValid[frame];
-        if ((int)(blockIdx.x * blockDim.x) >= n) return;
-        index = index < n ? validIdx[(size_t)frame * nPix + index] : nPix;
-    }
+    // with a list of the frame's valid pixels (gn_valid_pixels) the workgroups stride over the list instead of the map: the
+    // launch then needs only as many workgroups as fill the chip, not one per 256 pixels of which most would find nothing
+    const int nItems = validIdx ? nValid[frame] : nPix;
+    for (int k0 = blockIdx.x * blockDim.x; k0 < nItems; k0 += gridDim.x * blockDim.x) {
+    const int k = k0 + threadIdx.x;
+    const int index = validIdx ? (k < nItems ? validIdx[(size_t)frame * nPix + k] : nPix) : k;
     int aModel = -1, aGrid = -1;
     float sdfError = 1e20f;
     if (index < nPix) {
@@ -138,6 +138,7 @@ assoc_multi_kernel(const float4 *__restrict__ vert, int nPix, const MultiArgs *_
             p.index = index; p.dataAssociation = aGrid; p.error = sdfError;
             args->pts[mi][(size_t)frame * fb.pts + base + __popcll(mask & lt)] = p;
         }
+    }
     }
 }
 
@@ -400,7 +401,9 @@ int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void
                           const int *d_validIdx, const int *d_nValid) {
     const FrameBatch fb = cur_batch();
     DARTK_HIP(hipMemsetAsync(d_last, 0, (fb.n > 1 ? (size_t)fb.n * fb.counts : (size_t)nModels) * sizeof(int), st));
-    hipLaunchKernelGGL(assoc_multi_kernel<false>, dim3((nPix + 255) / 256, fb.n), dim3(256), 0, st, (const float4 *)d_vert, nPix,
+    int wgs = (nPix + 255) / 256;
+    if (d_validIdx) { const int cap = fb.n > 1 ? (8192 / fb.n > 16 ? 8192 / fb.n : 16) : 2048; if (wgs > cap) wgs = cap; }
+    hipLaunchKernelGGL(assoc_multi_kernel<false>, dim3(wgs, fb.n), dim3(256), 0, st, (const float4 *)d_vert, nPix,
                        (const MultiArgs *)d_args, d_last, nullptr, nullptr, fb, d_validIdx, d_nValid);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
