@@ -178,8 +178,9 @@ raycast_replay_multi_rows_kernel(float flx, float fly, float ppx, float ppy, int
         const int index = chunk * 256 + threadIdx.x;
         if (index >= nPix) continue;
         const int x = index % width, y = index / width;
-        float4 pr = prediction[index];
-        pr.z = 0; pr.w = -1;                        // model 0 starts the map (x, y keep what the map held, as there)
+        // model 0 starts the map. The reference leaves x, y of a pixel without a hit as they were; nothing reads them (every
+        // consumer tests z first), and this kernel only ever writes the loop's own scratch map, so they are not fetched
+        float4 pr = make_float4(0.f, 0.f, 0.f, -1.f);
         int off = 0;
         for (int mi = 0; mi < a.n; ++mi) {
             const int n = a.m[mi].nSdfs;

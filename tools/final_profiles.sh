@@ -1,0 +1,13 @@
+#!/bin/bash
+# The round's measurement passes on the GPU box (each step under its own limit; stops at the first failure):
+#   kernel stats, HBM read / write traffic (two PMC passes), L2 hit rate (one PMC pass), of the same bench command
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+CMD="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --grasp-steps 1 --repeats 0 --multi-steps 1"
+O=gpurun_out/final
+mkdir -p $O
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $CMD > $O/stats.log 2>&1
+timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $CMD > $O/fetch.log 2>&1
+timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $CMD > $O/write.log 2>&1
+timeout -s KILL 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $O/l2 -- $CMD > $O/l2.log 2>&1
+echo profiles done
