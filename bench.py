@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=24, help="further repeats of the timed K-step loop for the median / min / max line")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline (0 = OMP_NUM_THREADS or min(cpu_count, 16))")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=12, help="single-thread CPU sample: whole steps of the headline workload (about 5 s)")
     ap.add_argument("--norm-threshold", type=float, default=None, help="override the workload's normal gate (reference default -0.1)")
     ap.add_argument("--grasp-candidates", type=int, default=4096)
     ap.add_argument("--grasp-steps", type=int, default=3)
@@ -317,10 +317,10 @@ def main():
                 O.set_threads(1)
                 return n * iters / dt_
             one = time_cpu(1, args.cpu_steps)
-            many = time_cpu(nthr, max(args.cpu_steps, 2 * nthr // 4))
+            many = time_cpu(nthr, max(args.cpu_steps, 10 * nthr))
             sample = "whole steps (obs-SDF build + %d iterations) of the same 640x480 Allegro workload, CPU oracle (OpenMP over pixels / rays)" % iters
             cpu_baseline = {"value": round(many, 3), "unit": "GN iterations/s", "cores": nthr, "kind": "port", "cpu_model": cpu_model_name(),
-                            "sample": "%d %s, %d threads" % (max(args.cpu_steps, 2 * nthr // 4), sample, nthr),
+                            "sample": "%d %s, %d threads" % (max(args.cpu_steps, 10 * nthr), sample, nthr),
                             "single_thread": {"value": round(one, 3), "cores": 1, "sample": "%d %s, 1 thread" % (args.cpu_steps, sample)}}
 
     # ================================================================== BASELINE config 4: batched ContactGrasp refinement
@@ -409,12 +409,12 @@ def main():
                         with ThreadPoolExecutor(threads) as ex:
                             list(ex.map(one_candidate, range(n)))
                     return n * 10 / g_iters / (time.perf_counter() - tc0)
-                one = time_cpu(1, 16)
-                many = time_cpu(nthr, 16 * nthr)
+                one = time_cpu(1, 96)
+                many = time_cpu(nthr, 64 * nthr)
                 sample = "candidates x 10 of the %d iterations (+ getError), CPU oracle, scaled to %d iterations" % (g_iters, g_iters)
                 g_cpu = {"value": round(many, 4), "unit": "grasps/s", "cores": nthr, "kind": "port", "cpu_model": cpu_model_name(),
-                         "sample": "%d %s, %d threads (one candidate per thread)" % (16 * nthr, sample, nthr),
-                         "single_thread": {"value": round(one, 4), "cores": 1, "sample": "16 %s, 1 thread" % sample}}
+                         "sample": "%d %s, %d threads (one candidate per thread)" % (64 * nthr, sample, nthr),
+                         "single_thread": {"value": round(one, 4), "cores": 1, "sample": "96 %s, 1 thread" % sample}}
             grasps = {"metric": "batched ContactGrasp refinement", "value": round(n_cand * args.grasp_steps / g_elapsed, 2), "unit": "grasps/s",
                       "gn_iterations_per_s": round(n_cand * args.grasp_steps * g_iters / g_elapsed, 1),
                       "scaling": "strong", "n_candidates": n_cand, "candidates_per_gpu": len(idx), "iterations": g_iters,
