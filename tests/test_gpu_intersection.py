@@ -102,6 +102,7 @@ def test_reduced_intersection_variants(gpu):
     cloud = m.collision_cloud(1e5, seed=3)
     dm.set_pose(se3.identity(), closed_fist(m))
     _, T_mf, T_fm, _ = dm.get_transforms()
+    # the Barrett coupling pattern of grasp_analyzer.cpp:409-417 (all ones there) with Barrett.xml:17's 1/3 gear ratios as values
     A = np.zeros((8, 4), dtype=F)
     for f_, r, c in [(0, 0, 1), (3, 0, 1), (1, 1, 1), (2, 1, 1 / 3), (4, 2, 1), (5, 2, 1 / 3), (6, 3, 1), (7, 3, 1 / 3)]:
         A[f_, r] = c

@@ -154,7 +154,8 @@ def test_reduced_and_parammap_normal_equations(gpu):
     v_d = torch.from_numpy(vert).to(gpu)
     pts, count, _ = D.error_and_data_association(v_d, torch.from_numpy(norm).to(gpu), dm)
     o_pts, _ = O.assoc_single(vert, norm, om, T_mc, T_fm)
-    # Barrett's 8 -> 4 coupling (grasp_analyzer.cpp:409-417): A[r + f*4]
+    # a LinearPoseReduction with the Barrett coupling PATTERN (grasp_analyzer.cpp:409-417 sets the same entries, all to 1; the 1/3
+    # gear ratios used here live in Barrett.xml:17) -- non-unit entries make the test sensitive to A's values: A[r + f*4]
     A = np.zeros((8, 4), dtype=F)
     for f, r, c in [(0, 0, 1), (3, 0, 1), (1, 1, 1), (2, 1, 1 / 3), (4, 2, 1), (5, 2, 1 / 3), (6, 3, 1), (7, 3, 1 / 3)]:
         A[f, r] = c
