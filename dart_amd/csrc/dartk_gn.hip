@@ -191,11 +191,18 @@ fused_obs2mod_kernel(FusedObs2ModArgs fa, ModelView m) {
 // critical chain ~6 us of event handling (profiles/r02_timeline.txt), a quarter of a whole kernel. As one grid (workgroups
 // [0, nTraceWgs) walk the trace tasks, the rest take one tile of valid pixels each) they still run side by side, the whole
 // iteration stays on ONE stream, and kernels that follow each other on one stream start back to back.
-struct TraceArgs { float flx, fly, ppx, ppy; int width, height; float2 *trace; int nTraceWgs; };
+struct TraceArgs { float flx, fly, ppx, ppy; int width, height; float2 *trace; int nTraceWgs; float *tables; };
 template <int PPT>
 __global__ void __launch_bounds__(NE_BLOCK)
 trace_and_obs2mod_kernel(TraceArgs ta, FusedObs2ModArgs fa, ModelView m) {
     extern __shared__ float lds[];
+    if (blockIdx.x == gridDim.x - 1) {
+        // one more workgroup leaves this pose's replay tables (per-SDF ray transforms, tile rectangles) in memory for the mod->obs
+        // kernel that follows: its hundreds of workgroups then load 28 nSdfs + 1 words instead of each rebuilding them behind three
+        // barriers -- that prologue was most of what that kernel's launch cost
+        replay_tables_to_global(m, ta.flx, ta.fly, ta.ppx, ta.ppy, ta.width, ta.height, lds, ta.tables);
+        return;
+    }
     if ((int)blockIdx.x < ta.nTraceWgs) {       // the trace's stragglers are the launch's critical path: first in the grid
         int *sR = reinterpret_cast<int *>(lds);
         stage_ray_rects(m, 0.0f, ta.flx, ta.fly, ta.ppx, ta.ppy, ta.width, ta.height, sR);
@@ -747,7 +754,10 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
 
     const int nPred = o->predWidth * o->predHeight;
     const int tilesB = (nPred + NE_BLOCK - 1) / NE_BLOCK;
-    const int nBlocksB = tilesB < GN_MAX_BLOCKS ? tilesB : GN_MAX_BLOCKS;
+    static const char *envB = getenv("DARTK_M2O_TILES_PER_WG");       // diagnostic: tiles per mod->obs workgroup
+    const int tpw = envB ? atoi(envB) : 1;
+    const int wantB = (tilesB + tpw - 1) / tpw;
+    const int nBlocksB = wantB < GN_MAX_BLOCKS ? wantB : GN_MAX_BLOCKS;
     const int tilesC = (nCloud + NE_BLOCK - 1) / NE_BLOCK;
     const int nBlocksC = tilesC < GN_MAX_BLOCKS ? tilesC : GN_MAX_BLOCKS;
 
@@ -822,8 +832,9 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         const long long tasks = (long long)((o->predWidth + 7) / 8) * ((o->predHeight + 7) / 8) * m.nSdfs;
         const long long want = (tasks + NE_BLOCK / 64 - 1) / (NE_BLOCK / 64);
         ta = TraceArgs{o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2), o->predWidth, o->predHeight,
-                       (float2 *)ws->rayBuf, (int)(want < 2048 ? want : 2048)};
+                       (float2 *)ws->rayBuf, (int)(want < 2048 ? want : 2048), ws->sysScratch + 4 * kMaxSys};
         if (ldsU < sizeof(int) * kRectInts) ldsU = sizeof(int) * kRectInts;
+        if (ldsU < sizeof(float) * (28 * (size_t)m.nSdfs + 1)) ldsU = sizeof(float) * (28 * (size_t)m.nSdfs + 1);
     }
     for (int it = 0; it < o->numIterations; ++it) {
         if (sideA && it > 0) {      // the pose of this iteration is final on `st` (previous solve)
@@ -836,7 +847,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
             auto kfn = trace_and_obs2mod_kernel<PPT_>;                                                          \
             if (ldsU > 64 * 1024)                                                                               \
                 DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsU)); \
-            hipLaunchKernelGGL(kfn, dim3(ta.nTraceWgs + nBlocksA), dim3(NE_BLOCK), ldsU, st, ta, fa, m);        \
+            hipLaunchKernelGGL(kfn, dim3(ta.nTraceWgs + nBlocksA + 1), dim3(NE_BLOCK), ldsU, st, ta, fa, m);    \
         } else {                                                                                                \
             auto kfn = fused_obs2mod_kernel<PPT_>;                                                              \
             if (ldsA > 64 * 1024)                                                                               \
@@ -854,7 +865,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         if (useB) {
             rc = gn_launch_raycast_ne_mod2obs(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2),
                                               o->predWidth, o->predHeight, 0, m, d_prediction, d_T_gc, slabsB, nBlocksB, cntB, stB,
-                                              (fork && it == 0) ? ws->evObs : nullptr, unionAB);
+                                              (fork && it == 0) ? ws->evObs : nullptr, unionAB, unionAB ? ta.tables : nullptr);
             if (rc) return rc;
         }
         if (useA && !unionAB) {

@@ -34,19 +34,6 @@ raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int 
 
 static constexpr int RC_REPLAY_SDFS = 64;    // per-SDF transforms staged in LDS, this many at a time
 
-// camera->frame and frame->camera transforms of SDFs [s0, s0+nc) into sT (24 floats each); threads < nc work
-__device__ __forceinline__ void replay_stage_transforms(const ModelView &m, int s0, int nc, float *sT) {
-    if ((int)threadIdx.x < nc) {
-        const int f = m.sdfFrame[s0 + threadIdx.x];
-        float T_fm[12], T_mf[12], T_mc[12], T_cm[12], T_fc[12], T_cf[12];
-        for (int i = 0; i < 12; ++i) { T_fm[i] = m.T_fm[12 * f + i]; T_mf[i] = m.T_mf[12 * f + i]; T_mc[i] = m.T_mc[i]; }
-        se3_invert(T_mc, T_cm);                 // raycast.cu:143
-        se3_mul(T_fm, T_mc, T_fc);
-        se3_mul(T_cm, T_mf, T_cf);              // T_cm*T_mfs[f]
-        for (int i = 0; i < 12; ++i) { sT[24 * threadIdx.x + i] = T_fc[i]; sT[24 * threadIdx.x + 12 + i] = T_cf[i]; }
-    }
-}
-
 // the reference's sequential rule over SDFs [s0, s0+nc) for one pixel: a crossing counts iff it was detected before the
 // closest hit so far
 __device__ __forceinline__ void replay_pixel(float4 &pr, float &closestT, int x, int y, int nSdfs, const int *sR, int modelNum, int s0, int nc,
@@ -393,6 +380,9 @@ struct ReplayArgs {            // REPLAY variant: the prediction is formed in th
     int width, modelNum;       // modelNum: the label's model number (raycast.cu's modelNum argument)
     const float2 *trace;       // [nSdfs][nPix] {detection t, hit t}
     float4 *predOut;
+    // optional: this pose's [per-SDF ray transforms (24 nSdfs floats) | tile rectangles (4 nSdfs + 1 ints)] as an earlier kernel of
+    // the iteration left them (replay_tables_to_global): one coalesced load instead of recomputing them in every workgroup
+    const float *tables;
 };
 
 template <int PPT, int RED, bool TRUNC, bool REPLAY = false>
@@ -419,8 +409,14 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
     int *sR = reinterpret_cast<int *>(sRT + 24 * m.nSdfs);     // REPLAY: the tile rectangles of the sparse traces, 4 * nSdfs + 1 ints
     stage_model(m, sT_fm, sT_mf, nullptr);
     if (REPLAY) {       // nSdfs <= NE_BLOCK checked by the launcher; every thread reads sRT in the first tile already
-        replay_stage_transforms(m, 0, m.nSdfs, sRT);
-        stage_ray_rects(m, 0.0f, ra.flx, ra.fly, ra.ppx, ra.ppy, ra.width, nPix / ra.width, sR);
+        if (ra.tables) {
+            const int words = 28 * m.nSdfs + 1;
+            for (int i = threadIdx.x; i < words; i += blockDim.x) sRT[i] = ra.tables[i];      // (sR follows sRT in LDS as in the table)
+            __syncthreads();
+        } else {
+            replay_stage_transforms(m, 0, m.nSdfs, sRT);
+            stage_ray_rects(m, 0.0f, ra.flx, ra.fly, ra.ppx, ra.ppy, ra.width, nPix / ra.width, sR);
+        }
     }
     float T_gc[12];
 #pragma unroll
@@ -631,7 +627,7 @@ int gn_launch_raycast_replay_at(float flx, float fly, float ppx, float ppy, int 
 // traces (writing the prediction for the caller) and goes on with the pixel -- one launch less on the critical path
 int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                                  float *d_prediction, const float *d_T_gc, float *slabs, int nBlocks, int *d_num, hipStream_t st,
-                                 hipEvent_t beforeNe, bool traceDone) {
+                                 hipEvent_t beforeNe, bool traceDone, const float *d_tables) {
     // beforeNe: an event the normal-equation kernel (the first reader of the obs SDF and of T_gc) waits for; the
     // ray-cast needs neither and starts at once
     if (m.nSdfs > NE_BLOCK) {
@@ -653,7 +649,7 @@ int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int
     const int d = 6 + m.nJoints, S = sys_size(d), nPix = width * height;
     const size_t ldsBytes = ne_mod2obs_lds_bytes(m, d, 0) + sizeof(float) * (28 * (size_t)m.nSdfs + 1);
     DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
-    const ReplayArgs ra = {flx, fly, ppx, ppy, width, modelNum, (const float2 *)ws->rayBuf, (float4 *)d_prediction};
+    const ReplayArgs ra = {flx, fly, ppx, ppy, width, modelNum, (const float2 *)ws->rayBuf, (float4 *)d_prediction, d_tables};
     ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
 #define DARTK_LAUNCH_RM2O(PPT_)                                                                                 \
     do {                                                                                                        \

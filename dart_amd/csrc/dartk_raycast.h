@@ -114,6 +114,29 @@ __device__ __forceinline__ void stage_ray_rects(const ModelView &m, float levelS
     __syncthreads();
 }
 
+// camera->frame and frame->camera transforms of SDFs [s0, s0+nc) into sT (24 floats each); threads < nc work
+__device__ __forceinline__ void replay_stage_transforms(const ModelView &m, int s0, int nc, float *sT) {
+    if ((int)threadIdx.x < nc) {
+        const int f = m.sdfFrame[s0 + threadIdx.x];
+        float T_fm[12], T_mf[12], T_mc[12], T_cm[12], T_fc[12], T_cf[12];
+        for (int i = 0; i < 12; ++i) { T_fm[i] = m.T_fm[12 * f + i]; T_mf[i] = m.T_mf[12 * f + i]; T_mc[i] = m.T_mc[i]; }
+        se3_invert(T_mc, T_cm);                 // raycast.cu:143
+        se3_mul(T_fm, T_mc, T_fc);
+        se3_mul(T_cm, T_mf, T_cf);              // T_cm*T_mfs[f]
+        for (int i = 0; i < 12; ++i) { sT[24 * threadIdx.x + i] = T_fc[i]; sT[24 * threadIdx.x + 12 + i] = T_cf[i]; }
+    }
+}
+
+// [per-SDF ray transforms | tile rectangles] of the current pose -> `out` (28 nSdfs + 1 words, the layout ne_mod2obs_kernel's replay
+// keeps in LDS), by one whole workgroup; scratch: 28 nSdfs + 1 words of LDS. nSdfs <= blockDim.x.
+__device__ __forceinline__ void replay_tables_to_global(const ModelView &m, float flx, float fly, float ppx, float ppy, int width, int height,
+                                                        float *scratch, float *__restrict__ out) {
+    const int n = m.nSdfs;
+    replay_stage_transforms(m, 0, n, scratch);
+    stage_ray_rects(m, 0.0f, flx, fly, ppx, ppy, width, height, reinterpret_cast<int *>(scratch + 24 * n));      // (ends with a barrier)
+    for (int i = threadIdx.x; i < 28 * n + 1; i += blockDim.x) out[i] = scratch[i];
+}
+
 // the tasks firstTask, firstTask + taskStride, ... of one wave (sR: the table of stage_ray_rects, already staged and synced)
 __device__ __forceinline__ void raycast_trace_tasks(int firstTask, int taskStride, const int *sR, float flx, float fly, float ppx, float ppy,
                                                     int width, int height, const ModelView &m, float2 *__restrict__ trace, float levelSet) {
