@@ -540,11 +540,25 @@ __device__ __forceinline__ float assemble_solve_regs(const SolveArgs &a, int d, 
         const int o = lane + 64 * q;
         tc[q] = (a.sysC && o < Sa - 1) ? a.sysC[o] : 0.0f;
     }
-    for (int o = lane; o < S - 1; o += 64) {
-        float v = 0.0f;
-        if (a.sysA) v += a.lambdaA * a.sysA[o];
-        if (a.sysB) v += a.lambdaB * a.sysB[o];
-        W[o] = v;
+    {   // all loads of both systems first, then the sums: one memory round trip instead of one per 64 entries
+        constexpr int NI = (sys_size(NMAX) + 63) / 64;
+        float va[NI], vb[NI];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int o = lane + 64 * q;
+            va[q] = (a.sysA && o < S - 1) ? a.sysA[o] : 0.0f;
+            vb[q] = (a.sysB && o < S - 1) ? a.sysB[o] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int o = lane + 64 * q;
+            if (o < S - 1) {
+                float v = 0.0f;
+                if (a.sysA) v += a.lambdaA * va[q];
+                if (a.sysB) v += a.lambdaB * vb[q];
+                W[o] = v;
+            }
+        }
     }
     wave_sync();
     if (a.sysC) {
