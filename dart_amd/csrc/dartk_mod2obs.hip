@@ -33,27 +33,49 @@ raycast_trace_kernel(float flx, float fly, float ppx, float ppy, int width, int 
 }
 
 static constexpr int RC_REPLAY_SDFS = 64;    // per-SDF transforms staged in LDS, this many at a time
+static constexpr int RC_REPLAY_GROUP = 8;    // trace records requested together by the replay
 
 // the reference's sequential rule over SDFs [s0, s0+nc) for one pixel: a crossing counts iff it was detected before the
 // closest hit so far
+template <int GROUP = RC_REPLAY_GROUP>
 __device__ __forceinline__ void replay_pixel(float4 &pr, float &closestT, int x, int y, int nSdfs, const int *sR, int modelNum, int s0, int nc,
                                              const float *sT, const float2 *__restrict__ trace, float flx, float fly, float ppx, float ppy) {
     const int tx = x >> 3, ty = y >> 3, sub = (y & 7) * 8 + (x & 7);
-    for (int k = 0; k < nc; ++k) {
-        const int s = s0 + k;
-        const int rx = tx - sR[s], ry = ty - sR[nSdfs + s], rw = sR[2 * nSdfs + s];
-        const int off = sR[3 * nSdfs + s], cnt = sR[3 * nSdfs + s + 1] - off;
-        // outside the SDF's rectangle nothing was traced: "no crossing"
-        if (rx < 0 || ry < 0 || rx >= rw || ry * rw + rx >= cnt) continue;
-        const float2 dh = trace[(size_t)(off + ry * rw + rx) * 64 + sub];
-        if (dh.x < closestT) {
-            const float tHit = dh.y;
-            const RayGeom g = ray_in_frame(sT + 24 * k, x, y, flx, fly, ppx, ppy);
-            const f3 xc = se3_apply_w(sT + 24 * k + 12, g.dn.x * tHit + g.of.x, g.dn.y * tHit + g.of.y, g.dn.z * tHit + g.of.z, 1.0f);
-            if (pr.z == 0 || xc.z < pr.z) {
-                pr.x = xc.x; pr.y = xc.y; pr.z = xc.z; pr.w = (float)((modelNum << 16) + s);
+    // The rule is sequential in the SDF index, the trace records it reads are not: the records of GROUP SDFs are
+    // requested together (one memory round trip instead of one per SDF whose rectangle holds the pixel), then judged in order.
+    for (int k0 = 0; k0 < nc; k0 += GROUP) {
+        float2 dh[GROUP];
+#pragma unroll
+        for (int g = 0; g < GROUP; ++g) {
+            const int k = k0 + g, s = s0 + k;
+            dh[g] = make_float2(3.0e38f, 0.0f);      // outside the SDF's rectangle nothing was traced: "no crossing"
+            if (k < nc) {
+                const int rx = tx - sR[s], ry = ty - sR[nSdfs + s], rw = sR[2 * nSdfs + s];
+                const int off = sR[3 * nSdfs + s], cnt = sR[3 * nSdfs + s + 1] - off;
+                if (!(rx < 0 || ry < 0 || rx >= rw || ry * rw + rx >= cnt)) dh[g] = trace[(size_t)(off + ry * rw + rx) * 64 + sub];
             }
-            closestT = tHit;
+        }
+        // A pixel has a crossing with few of the SDFs, a wave of 64 pixels with most of them: each lane walks ITS crossings
+        // (ascending SDF index, as the rule wants), so the wave takes as many turns as its busiest lane has crossings, not
+        // one per SDF that any lane crosses.
+        unsigned live = 0u;
+#pragma unroll
+        for (int g = 0; g < GROUP; ++g) live |= (dh[g].x < 3.0e38f) ? (1u << g) : 0u;
+        while (live) {
+            const int g = __builtin_ctz(live);
+            live &= live - 1u;
+            float det = dh[0].x, tHit = dh[0].y;
+#pragma unroll
+            for (int q = 1; q < GROUP; ++q) { det = (g == q) ? dh[q].x : det; tHit = (g == q) ? dh[q].y : tHit; }
+            if (det < closestT) {
+                const int k = k0 + g, s = s0 + k;
+                const RayGeom gm = ray_in_frame(sT + 24 * k, x, y, flx, fly, ppx, ppy);
+                const f3 xc = se3_apply_w(sT + 24 * k + 12, gm.dn.x * tHit + gm.of.x, gm.dn.y * tHit + gm.of.y, gm.dn.z * tHit + gm.of.z, 1.0f);
+                if (pr.z == 0 || xc.z < pr.z) {
+                    pr.x = xc.x; pr.y = xc.y; pr.z = xc.z; pr.w = (float)((modelNum << 16) + s);
+                }
+                closestT = tHit;
+            }
         }
     }
 }
@@ -375,6 +397,12 @@ __global__ void dt_combine_kernel(float *__restrict__ im, const float *__restric
 // are compacted (deterministically) into LDS rows before the pair reduction, so empty image regions cost one
 // ballot. RED: 0 full, 1 linear, 2 param map. TRUNC: truncation window (modToObs.cu:163-166).
 // -----------------------------------------------------------------------------------------------------
+#ifdef DARTK_STAMPS
+__device__ unsigned long long g_m2oStamps[1024 * 8];     // per workgroup of the last launch: realtime ticks (10 ns) at the phase boundaries
+#define M2O_STAMP(i) do { stp[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define M2O_STAMP(i) do { } while (0)
+#endif
 struct ReplayArgs {            // REPLAY variant: the prediction is formed in the kernel from the ray-cast traces
     float flx, fly, ppx, ppy;
     int width, modelNum;       // modelNum: the label's model number (raycast.cu's modelNum argument)
@@ -391,6 +419,10 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
                   float truncationDist, int redDims, const float *__restrict__ dtheta_dalpha, const int *__restrict__ mapping,
                   float *__restrict__ slabs, int *__restrict__ numPredictions, ReplayArgs ra, FrameBatch fb, int tgcStride) {
     extern __shared__ float lds[];
+#ifdef DARTK_STAMPS
+    unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    M2O_STAMP(0);
     ModelView m = m_in;
     select_frame(m, blockIdx.y);                    // frame of a batch (0 otherwise)
     pred += (size_t)blockIdx.y * fb.pred;
@@ -405,13 +437,41 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
     float *sFull = sT_mf + 12 * m.nFrames;
     float *rows = sFull + (RED ? NE_BLOCK * fullLd : 0);
     int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ld);
-    float *sRT = reinterpret_cast<float *>(waveCnt + 8);       // REPLAY: per-SDF ray transforms, 24 * nSdfs floats
+    unsigned *sDep = reinterpret_cast<unsigned *>(waveCnt + 8);    // each frame's dependency mask (low, high word)
+    int *sFrameOf = reinterpret_cast<int *>(sDep + 2 * m.nFrames);  // each SDF's frame
+    float *sRT = reinterpret_cast<float *>(sFrameOf + m.nSdfs);     // REPLAY: per-SDF ray transforms, 24 * nSdfs floats
     int *sR = reinterpret_cast<int *>(sRT + 24 * m.nSdfs);     // REPLAY: the tile rectangles of the sparse traces, 4 * nSdfs + 1 ints
-    stage_model(m, sT_fm, sT_mf, nullptr);
+    // Everything the workgroup stages is requested before anything is waited for: the frame transforms, the replay tables and
+    // the first tile's prediction pixel travel together (one memory round trip; a loop of load -> LDS store pays one per turn)
+    constexpr int QS = 4;
+    const int nT = 12 * m.nFrames, nTab = (REPLAY && ra.tables) ? 28 * m.nSdfs + 1 : 0;
+    const bool batched = nT <= QS * NE_BLOCK && nTab <= QS * NE_BLOCK;
+    float4 pcFirst = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (REPLAY && blockIdx.x * NE_BLOCK + (int)threadIdx.x < nPix) pcFirst = ra.predOut[blockIdx.x * NE_BLOCK + threadIdx.x];
+    // the label -> frame -> dependency-mask chain of a contributing pixel is served from LDS
+    for (int i = threadIdx.x; i < 2 * m.nFrames + m.nSdfs; i += NE_BLOCK)
+        sDep[i] = i < 2 * m.nFrames ? reinterpret_cast<const unsigned *>(m.depMask)[i] : (unsigned)m.sdfFrame[i - 2 * m.nFrames];
+    if (batched) {
+        float vf[QS], vm[QS], vt[QS];
+#pragma unroll
+        for (int q = 0; q < QS; ++q) {
+            const int i = threadIdx.x + q * NE_BLOCK;
+            vf[q] = i < nT ? m.T_fm[i] : 0.0f;
+            vm[q] = i < nT ? m.T_mf[i] : 0.0f;
+            vt[q] = i < nTab ? ra.tables[i] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < QS; ++q) {
+            const int i = threadIdx.x + q * NE_BLOCK;
+            if (i < nT) { sT_fm[i] = vf[q]; sT_mf[i] = vm[q]; }
+            if (i < nTab) sRT[i] = vt[q];                       // (sR follows sRT in LDS as in the table)
+        }
+    } else {
+        stage_model(m, sT_fm, sT_mf, nullptr);
+        for (int i = threadIdx.x; i < nTab; i += blockDim.x) sRT[i] = ra.tables[i];
+    }
     if (REPLAY) {       // nSdfs <= NE_BLOCK checked by the launcher; every thread reads sRT in the first tile already
         if (ra.tables) {
-            const int words = 28 * m.nSdfs + 1;
-            for (int i = threadIdx.x; i < words; i += blockDim.x) sRT[i] = ra.tables[i];      // (sR follows sRT in LDS as in the table)
             __syncthreads();
         } else {
             replay_stage_transforms(m, 0, m.nSdfs, sRT);
@@ -427,6 +487,7 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
     PairAcc<NE_BLOCK, PPT> acc;
     acc.init(d, false);
     int myCount = 0;
+    M2O_STAMP(1);
     const int nTiles = (nPix + NE_BLOCK - 1) / NE_BLOCK;
     for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
         const int index = tile * NE_BLOCK + threadIdx.x;
@@ -437,15 +498,18 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
         if (index < nPix) {
             float4 pc;
             if (REPLAY) {       // the pixel's prediction is formed here from the per-SDF traces and kept for the caller
-                pc = ra.predOut[index];
+                pc = tile == (int)blockIdx.x ? pcFirst : ra.predOut[index];
+                M2O_STAMP(2);
                 if (ra.modelNum == 0) { pc.z = 0; pc.w = -1; }
                 float closestT = 10000;
-                replay_pixel(pc, closestT, index % ra.width, index / ra.width, m.nSdfs, sR, ra.modelNum, 0, m.nSdfs, sRT, ra.trace,
+                replay_pixel<24>(pc, closestT, index % ra.width, index / ra.width, m.nSdfs, sR, ra.modelNum, 0, m.nSdfs, sRT, ra.trace,
                              ra.flx, ra.fly, ra.ppx, ra.ppy);
+                M2O_STAMP(3);
                 ra.predOut[index] = pc;
             } else {
                 pc = pred[index];
             }
+            M2O_STAMP(4);
             if (pc.z != 0) {
                 f3 p3; p3.x = pc.x; p3.y = pc.y; p3.z = pc.z;
                 pm = se3_apply(T_gc, p3);
@@ -457,37 +521,45 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
                     if (ok) {
                         const int label = (int)roundf(pc.w);
                         if ((label >> 16) == modelNum) {
-                            frame = m.sdfFrame[label & 65535];
+                            frame = sFrameOf[label & 65535];
                             active = true;
                         }
                     }
                 }
             }
         }
+        M2O_STAMP(5);
         int nActive;
         const int slot = compact_slot<NE_BLOCK>(active, waveCnt, nActive);
         if (active) {
             float *row = rows + slot * ld;
             const f3 gm = grid_gradient<CNT_M2O>(obsData, obs.dimx, obs.dimy, pg);
             float *Jfull = RED ? (sFull + threadIdx.x * fullLd) : row;
-            error_jacobian<false>(Jfull, pm, 1.0f, m.depMask[frame], gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
+            const unsigned long long dep = (unsigned long long)sDep[2 * frame] | ((unsigned long long)sDep[2 * frame + 1] << 32);
+            error_jacobian<false>(Jfull, pm, 1.0f, dep, gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
             if (RED) reduce_jacobian<RED>(row, Jfull, 6, fullDims, redDims, dtheta_dalpha, mapping);
             row[d] = residual;
             row[d + 1] = (float)(0.5 * (double)residual * (double)residual);
             row[d + 2] = 1.0f;
         }
         __syncthreads();
+        M2O_STAMP(6);
         if (nActive) acc.accumulate(rows, ld, nActive);
         myCount += nActive;
         __syncthreads();
     }
     acc.store(slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * sys_size(d), sys_size(d));
     if (threadIdx.x == 0 && myCount) atomicAdd(numPredictions, myCount);
+#ifdef DARTK_STAMPS
+    M2O_STAMP(7);
+    if (REPLAY && threadIdx.x == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < 8; ++i) g_m2oStamps[8 * blockIdx.x + i] = stp[i];
+#endif
 }
 
 size_t ne_mod2obs_lds_bytes(const ModelView &m, int d, int red) {
     const int fullDims = 6 + m.nJoints;
-    size_t words = 24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8;
+    size_t words = 24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8 + 2 * (size_t)m.nFrames + m.nSdfs;
     if (red) words += (size_t)NE_BLOCK * (fullDims | 1);
     return words * sizeof(float);
 }
@@ -718,6 +790,12 @@ using namespace dartk;
 extern "C" {
 
 #ifdef DARTK_STAMPS
+// out[1024][8]: the last mod->obs launch's per-workgroup stamps
+int dartk_debug_m2o_phases(long long *out) {
+    DARTK_HIP(hipDeviceSynchronize());
+    DARTK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_m2oStamps), sizeof(unsigned long long) * 1024 * 8));
+    return DARTK_OK;
+}
 int dartk_debug_ray_steps(long long *out3) {
     int mx = 0; unsigned long long st = 0, n = 0;
     DARTK_HIP(hipDeviceSynchronize());
