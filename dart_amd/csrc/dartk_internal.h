@@ -419,6 +419,45 @@ __device__ __forceinline__ void error_jacobian(float *J, f3 pm, float pw, unsign
     }
 }
 
+// The same entries with each lane walking only the joints of ITS chain (a hand's finger link depends on 4 of 16 joints; the
+// lanes of a wave sit on different fingers, so the loop above runs the full body for nearly every joint). jointType /
+// jointAxis are indexed per lane here: pass LDS copies. Entry for entry the arithmetic of error_jacobian.
+template <bool ARTIC_ONLY>
+__device__ __forceinline__ void error_jacobian_walk(float *J, f3 pm, float pw, unsigned long long depMask, f3 grad, int nJoints,
+                                                    const int *sJointType, const float *sJointAxis, const float *T_fm,
+                                                    const float *T_mf) {
+    float *Ja = J;
+    if (!ARTIC_ONLY) {
+        J[0] = grad.x * -1.0f + grad.y * 0.0f + grad.z * 0.0f;
+        J[1] = grad.x * 0.0f + grad.y * -1.0f + grad.z * 0.0f;
+        J[2] = grad.x * 0.0f + grad.y * 0.0f + grad.z * -1.0f;
+        J[3] = grad.x * 0.0f + grad.y * pm.z + grad.z * -pm.y;
+        J[4] = grad.x * -pm.z + grad.y * 0.0f + grad.z * pm.x;
+        J[5] = grad.x * pm.y + grad.y * -pm.x + grad.z * 0.0f;
+        Ja = J + 6;
+    }
+    for (int i = 0; i < nJoints; ++i) Ja[i] = 0.0f;
+    unsigned long long todo = nJoints < 64 ? depMask & ((1ull << nJoints) - 1ull) : depMask;
+    while (todo) {
+        const int i = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int jf = i + 1;
+        const float *Tm = T_mf + 12 * jf;
+        f3 ax; ax.x = sJointAxis[3 * i]; ax.y = sJointAxis[3 * i + 1]; ax.z = sJointAxis[3 * i + 2];
+        float v;
+        if (sJointType[i] == 0) {
+            const f3 rel = se3_apply_w(T_fm + 12 * jf, pm.x, pm.y, pm.z, pw);
+            const f3 dxa = cross(ax, rel);
+            const f3 dx = se3_rotate(Tm, dxa);
+            v = dot(grad, dx);
+        } else {
+            const f3 axm = se3_rotate(Tm, ax);
+            v = dot(grad, axm);
+        }
+        Ja[i] = v;
+    }
+}
+
 #endif  // __HIPCC__
 
 }  // namespace dartk

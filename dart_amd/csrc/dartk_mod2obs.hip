@@ -439,7 +439,9 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
     int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ld);
     unsigned *sDep = reinterpret_cast<unsigned *>(waveCnt + 8);    // each frame's dependency mask (low, high word)
     int *sFrameOf = reinterpret_cast<int *>(sDep + 2 * m.nFrames);  // each SDF's frame
-    float *sRT = reinterpret_cast<float *>(sFrameOf + m.nSdfs);     // REPLAY: per-SDF ray transforms, 24 * nSdfs floats
+    int *sJType = sFrameOf + m.nSdfs;                               // joint types and axes, indexed per lane by the Jacobian walk
+    float *sJAxis = reinterpret_cast<float *>(sJType + m.nJoints);
+    float *sRT = sJAxis + 3 * m.nJoints;                            // REPLAY: per-SDF ray transforms, 24 * nSdfs floats
     int *sR = reinterpret_cast<int *>(sRT + 24 * m.nSdfs);     // REPLAY: the tile rectangles of the sparse traces, 4 * nSdfs + 1 ints
     // Everything the workgroup stages is requested before anything is waited for: the frame transforms, the replay tables and
     // the first tile's prediction pixel travel together (one memory round trip; a loop of load -> LDS store pays one per turn)
@@ -451,6 +453,10 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
     // the label -> frame -> dependency-mask chain of a contributing pixel is served from LDS
     for (int i = threadIdx.x; i < 2 * m.nFrames + m.nSdfs; i += NE_BLOCK)
         sDep[i] = i < 2 * m.nFrames ? reinterpret_cast<const unsigned *>(m.depMask)[i] : (unsigned)m.sdfFrame[i - 2 * m.nFrames];
+    for (int i = threadIdx.x; i < 4 * m.nJoints; i += NE_BLOCK) {
+        if (i < m.nJoints) sJType[i] = m.jointType[i];
+        else sJAxis[i - m.nJoints] = m.jointAxis[i - m.nJoints];
+    }
     if (batched) {
         float vf[QS], vm[QS], vt[QS];
 #pragma unroll
@@ -536,7 +542,7 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
             const f3 gm = grid_gradient<CNT_M2O>(obsData, obs.dimx, obs.dimy, pg);
             float *Jfull = RED ? (sFull + threadIdx.x * fullLd) : row;
             const unsigned long long dep = (unsigned long long)sDep[2 * frame] | ((unsigned long long)sDep[2 * frame + 1] << 32);
-            error_jacobian<false>(Jfull, pm, 1.0f, dep, gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
+            error_jacobian_walk<false>(Jfull, pm, 1.0f, dep, gm, m.nJoints, sJType, sJAxis, sT_fm, sT_mf);
             if (RED) reduce_jacobian<RED>(row, Jfull, 6, fullDims, redDims, dtheta_dalpha, mapping);
             row[d] = residual;
             row[d + 1] = (float)(0.5 * (double)residual * (double)residual);
@@ -559,7 +565,7 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
 
 size_t ne_mod2obs_lds_bytes(const ModelView &m, int d, int red) {
     const int fullDims = 6 + m.nJoints;
-    size_t words = 24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8 + 2 * (size_t)m.nFrames + m.nSdfs;
+    size_t words = 24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8 + 2 * (size_t)m.nFrames + m.nSdfs + 4 * (size_t)m.nJoints;
     if (red) words += (size_t)NE_BLOCK * (fullDims | 1);
     return words * sizeof(float);
 }
