@@ -422,7 +422,7 @@ __device__ __forceinline__ void error_jacobian(float *J, f3 pm, float pw, unsign
 // The same entries with each lane walking only the joints of ITS chain (a hand's finger link depends on 4 of 16 joints; the
 // lanes of a wave sit on different fingers, so the loop above runs the full body for nearly every joint). jointType /
 // jointAxis are indexed per lane here: pass LDS copies. Entry for entry the arithmetic of error_jacobian.
-template <bool ARTIC_ONLY>
+template <bool ARTIC_ONLY, bool ZERO = true>
 __device__ __forceinline__ void error_jacobian_walk(float *J, f3 pm, float pw, unsigned long long depMask, f3 grad, int nJoints,
                                                     const int *sJointType, const float *sJointAxis, const float *T_fm,
                                                     const float *T_mf) {
@@ -436,7 +436,8 @@ __device__ __forceinline__ void error_jacobian_walk(float *J, f3 pm, float pw, u
         J[5] = grad.x * pm.y + grad.y * -pm.x + grad.z * 0.0f;
         Ja = J + 6;
     }
-    for (int i = 0; i < nJoints; ++i) Ja[i] = 0.0f;
+    if (ZERO)       // (false: the caller has cleared the row)
+        for (int i = 0; i < nJoints; ++i) Ja[i] = 0.0f;
     unsigned long long todo = nJoints < 64 ? depMask & ((1ull << nJoints) - 1ull) : depMask;
     while (todo) {
         const int i = __builtin_ctzll(todo);

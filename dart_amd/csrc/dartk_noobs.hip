@@ -185,7 +185,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         sOff[nModels] = o;
         for (int mi = 0; mi < nModels; ++mi) { sSphOff[mi] = o; o += kSphereStride * P->model[mi].nSdfs; }
         sSphOff[nModels] = o;
-        for (int mi = 0; mi < nModels; ++mi) { sSdfOff[mi] = o; o += (kSdfWords + 1) * P->model[mi].nSdfs + 24; }
+        for (int mi = 0; mi < nModels; ++mi) { sSdfOff[mi] = o; o += (kSdfWords + 1) * P->model[mi].nSdfs + 24 + 4 * P->model[mi].nJoints; }
         sSdfOff[nModels] = o;
     }
     __syncthreads();
@@ -201,6 +201,11 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         const float *pose = poseC + P->poseOff[mi];         // the candidate's [T_mc | T_cm] of this model
         float *pp = lds + sSdfOff[mi] + (kSdfWords + 1) * mv.nSdfs;
         for (int i = threadIdx.x; i < 24; i += blockDim.x) pp[i] = pose[i];
+        // joint types and axes: the Jacobian rows index them per lane (error_jacobian_walk)
+        int *jt = reinterpret_cast<int *>(pp + 24);
+        float *ja = pp + 24 + mv.nJoints;
+        for (int i = threadIdx.x; i < mv.nJoints; i += blockDim.x) jt[i] = mv.jointType[i];
+        for (int i = threadIdx.x; i < 3 * mv.nJoints; i += blockDim.x) ja[i] = mv.jointAxis[i];
     }
     for (int mi = 0; mi < nModels; ++mi) {
         float *p = lds + sOff[mi];
@@ -213,6 +218,8 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
 #define sSdf(mi) (reinterpret_cast<const SdfDev *>(lds + sSdfOff[mi]))
 #define sFrm(mi, nSdfs_) (reinterpret_cast<const int *>(lds + sSdfOff[mi]) + kSdfWords * (nSdfs_))
 #define sPoseT(mi, nSdfs_) (lds + sSdfOff[mi] + (kSdfWords + 1) * (nSdfs_))      /* T_mc at +0, T_cm at +12 */
+#define sJType(mi, nSdfs_) (reinterpret_cast<const int *>(sPoseT(mi, nSdfs_) + 24))
+#define sJAxis(mi, nSdfs_, nJoints_) (sPoseT(mi, nSdfs_) + 24 + (nJoints_))
     __syncthreads();
     // bounding spheres of every SDF's keep boxes in its model's frame (see make_spheres)
     for (int mi = 0; mi < nModels; ++mi) {
@@ -282,12 +289,14 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                 // subJ(i) = dot(grad, J3D[i]) for i < getReducedDimensions(), J3D being the FULL Jacobian): for a reduced pose
                 // that is the first 6 + redArt columns of the full Jacobian, kept as the reference computes it
                 if (upSrc)
-                    error_jacobian<false>(L + P->off[pSrc], pm, 1.0f, ms.depMask[srcFrame], gs, P->dims[pSrc] - 6, ms.jointType, ms.jointAxis,
-                                          sTf(pSrc), sTf(pSrc) + 12 * ms.nFrames);
+                    error_jacobian_walk<false, false>(L + P->off[pSrc], pm, 1.0f, ms.depMask[srcFrame], gs, P->dims[pSrc] - 6,
+                                                      sJType(pSrc, ms.nSdfs), sJAxis(pSrc, ms.nSdfs, ms.nJoints), sTf(pSrc),
+                                                      sTf(pSrc) + 12 * ms.nFrames);
                 if (upDst) {
                     float *rd = L + P->off[pDst];
-                    error_jacobian<false>(rd, pdm, 1.0f, md.depMask[dstFrame], gdm, P->dims[pDst] - 6, md.jointType, md.jointAxis,
-                                          sTf(pDst), sTf(pDst) + 12 * md.nFrames);
+                    error_jacobian_walk<false, false>(rd, pdm, 1.0f, md.depMask[dstFrame], gdm, P->dims[pDst] - 6,
+                                                      sJType(pDst, md.nSdfs), sJAxis(pDst, md.nSdfs, md.nJoints), sTf(pDst),
+                                                      sTf(pDst) + 12 * md.nFrames);
                     const int nd = P->dims[pDst];
                     for (int i = 0; i < nd; ++i) rd[i] = -rd[i];
                 }
@@ -301,12 +310,12 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                 for (int i = d + 3; i < ld; ++i) row[i] = 0.0f;
                 const int red = P->redType[T.src];
                 if (red == 0) {
-                    error_jacobian<TYPE == TERM_SELF>(row + 2, pm, 1.0f, src.depMask[packed], gs, src.nJoints, src.jointType, src.jointAxis,
-                                                      sTf(T.src), sTf(T.src) + 12 * src.nFrames);
+                    error_jacobian_walk<TYPE == TERM_SELF>(row + 2, pm, 1.0f, src.depMask[packed], gs, src.nJoints, sJType(T.src, src.nSdfs),
+                                                           sJAxis(T.src, src.nSdfs, src.nJoints), sTf(T.src), sTf(T.src) + 12 * src.nFrames);
                 } else {        // normEqns*Reduced / *ParamMap (intersection.cu:147-300, 445-597): full Jacobian, then its reduction
                     float *Jf = sFullJ + threadIdx.x * fullLd;
-                    error_jacobian<TYPE == TERM_SELF>(Jf, pm, 1.0f, src.depMask[packed], gs, src.nJoints, src.jointType, src.jointAxis,
-                                                      sTf(T.src), sTf(T.src) + 12 * src.nFrames);
+                    error_jacobian_walk<TYPE == TERM_SELF>(Jf, pm, 1.0f, src.depMask[packed], gs, src.nJoints, sJType(T.src, src.nSdfs),
+                                                           sJAxis(T.src, src.nSdfs, src.nJoints), sTf(T.src), sTf(T.src) + 12 * src.nFrames);
                     const int fullDims = 6 + src.nJoints, redDims = P->dims[T.src];
                     if (red == 1) reduce_jacobian<1>(row + 2, Jf, TYPE == TERM_SELF ? 0 : 6, fullDims, redDims, P->redA[T.src], nullptr);
                     else reduce_jacobian<2>(row + 2, Jf, TYPE == TERM_SELF ? 0 : 6, fullDims, redDims, nullptr, P->redMap[T.src]);
@@ -920,7 +929,7 @@ int dartk_noobs_create_reduced(int nModels, const dartk_model_t *models, const d
     int nTerms = 0, slabOff = 0, SMax = 0;
     int ldsModels = 0, potInts = 0;
     for (int m = 0; m < nModels; ++m) {
-        ldsModels += 24 * P.model[m].nFrames + kSphereStride * P.model[m].nSdfs + (kSdfWords + 1) * P.model[m].nSdfs + 24;
+        ldsModels += 24 * P.model[m].nFrames + kSphereStride * P.model[m].nSdfs + (kSdfWords + 1) * P.model[m].nSdfs + 24 + 4 * P.model[m].nJoints;
         if (P.model[m].nSdfs * P.model[m].nSdfs > potInts) potInts = P.model[m].nSdfs * P.model[m].nSdfs;
     }
     t->potLdsInts = potInts <= 4096 ? potInts : 0;
