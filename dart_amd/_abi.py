@@ -61,7 +61,7 @@ class MultiModelC(C.Structure):
                 ("h_b", C.POINTER(C.c_float)), ("h_redMin", C.POINTER(C.c_float)), ("h_redMax", C.POINTER(C.c_float)),
                 ("d_redArt", C.c_void_p), ("d_cloud", C.c_void_p), ("nCloud", C.c_int32), ("d_potential", C.c_void_p),
                 ("d_pts", C.c_void_p), ("distThreshold", C.c_float), ("planeOffset", C.c_float), ("planeNormal", C.c_float * 3),
-                ("regularization", C.c_float), ("regularizationScaled", C.c_float)]
+                ("regularization", C.c_float), ("regularizationScaled", C.c_float), ("d_damping", C.c_void_p)]
 
 
 class MultiOptionsC(C.Structure):
@@ -218,6 +218,7 @@ def _load(path):
                                        C.POINTER(ContactPriorC), C.c_int, C.c_int, C.POINTER(vp)],
         "dartk_noobs_destroy": [vp],
         "dartk_noobs_set_priors": [vp, C.POINTER(ContactPriorC), C.c_int, vp],
+        "dartk_noobs_set_damping": [vp, C.c_int, C.POINTER(C.c_float), vp],
         "dartk_noobs_set_point_priors": [vp, C.POINTER(PointPriorC), C.c_int, vp],
         "dartk_optimize_poses": [C.POINTER(MultiOptionsC), C.POINTER(MultiModelC), vp, vp, C.c_int, C.c_int, vp, vp, vp, vp],
         "dartk_optimize_poses_priors": [C.POINTER(MultiOptionsC), C.POINTER(MultiModelC), vp, C.POINTER(ContactPriorC), C.c_int, vp, vp, C.c_int,

@@ -28,6 +28,7 @@ struct MultiSolveModel {
     float lamSelf, lamI[DARTK_MAX_MODELS];
     const int *countA, *countB;
     float reg, regScaled;
+    const float *damping;                   // [dims][dims] or null (Tracker::getDampingMatrix)
 };
 struct MultiSolveArgs {
     int nModels, D, numIterations;
@@ -246,7 +247,10 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration) {
         wave_sync_lds();
         for (int idx = lane; idx < dims * dims; idx += 64) {
             const int i = idx / dims, j = idx - i * dims;
-            if (j >= i) U[(off + i) * ldU + off + j] = J[i * ldU + j];
+            if (j < i) continue;
+            float v = J[i * ldU + j];
+            if (m.damping) v += m.damping[idx];                     // JTJ += *dampingMatrices[m]  (:702-703)
+            U[(off + i) * ldU + off + j] = v;
         }
         for (int i = lane; i < dims; i += 64) bv[off + i] = eJ[i];
         wave_sync_lds();
@@ -443,6 +447,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         s.redMax = fl + tables.size();
         for (int r = 0; r < redArt; ++r) tables.push_back(mm[m].h_redMax[r]);
         s.reg = mm[m].regularization; s.regScaled = mm[m].regularizationScaled;
+        s.damping = mm[m].d_damping;
         s.countA = useA ? d_countA + m : nullptr;
         s.countB = useB ? d_countB + m : nullptr;
         ptsList[m] = batch ? reinterpret_cast<dartk_da_point *>((char *)base + o_pts) + (size_t)m * nPix * nFrames : mm[m].d_pts;

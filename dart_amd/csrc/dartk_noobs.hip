@@ -594,6 +594,7 @@ struct NoObsSolveArgs {
     float *energy;        // [batch]
     float *iterInfo;      // [batch][numIterations][8] or null
     float *firstSystem;   // [batch][D*D + D] or null (iteration 0 only)
+    const float *damping[DARTK_MAX_MODELS];   // [dims][dims] per model or null (TrackerNoObs::getDampingMatrix)
 };
 
 __device__ __forceinline__ float reduce_slot(const float *slabs, int nBlocks, int S, int o) {
@@ -617,8 +618,25 @@ noobs_solve_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     for (int i = lane; i < D * ld; i += 64) U[i] = 0.0f;
     for (int i = lane; i < D; i += 64) b[i] = 0.0f;
     float eInt = 0.0f, ePri = 0.0f;
+    // JTJ += *dampingMatrices[m] (optimizer.cpp:895-896): onto the model blocks once their intersection terms are in, before
+    // the first prior contributes (the term table lists the priors last)
+    bool damped = a.energyOnly != 0;
+    auto add_damping = [&]() {
+        damped = true;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int mi = 0; mi < nModels; ++mi) {
+            const float *dm = a.damping[mi];
+            if (!dm) continue;
+            const int dims = P->dims[mi], off = P->off[mi];
+            for (int idx = lane; idx < dims * dims; idx += 64) {
+                const int i = idx / dims, j = idx - i * dims;
+                if (j >= i) U[(off + i) * ld + off + j] += dm[idx];
+            }
+        }
+    };
     for (int t = 0; t < P->nTerms; ++t) {
         const NoObsTerm &T = P->term[t];
+        if (!damped && term_weighted(T.type)) add_damping();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (int o = lane; o < T.S; o += 64) sys[o] = reduce_slot(slabC + T.slabOff, T.nBlocks, T.S, o);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -647,6 +665,7 @@ noobs_solve_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
             eInt += lam * sys[T.S - 1];       // getError sums the terms (:1047,1055)
         }
     }
+    if (!damped) add_damping();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int nPriorsAll = P->nPriors + P->nPointPriors;     // pe / priors.size(), optimizer.cpp:1068
     const float energy = eInt + (nPriorsAll > 0 ? ePri / (float)nPriorsAll : 0.0f);
@@ -759,6 +778,8 @@ struct NoObs {
     int ldsModels, slabFloats;     // LDS floats of the staged model tables; slab floats per candidate of the fixed terms
     float *poses, *slabs;
     float *contactPts;         // [maxBatch][nPriors][3] when a prior updates its contact point, else null
+    float *d_damping[DARTK_MAX_MODELS];     // damping matrices [dims][dims] (allocated by dartk_noobs_set_damping), null = zero
+    bool dampingOn[DARTK_MAX_MODELS];
     bool anyUpdate;
     int termFlags;             // NOOBS_* flags of the next terms launch
     int SMax, maxFrames, potLdsInts;
@@ -838,6 +859,8 @@ int dartk_noobs_destroy(dartk_noobs_t h) {
     if (t->d_pointPriors) (void)hipFree(t->d_pointPriors);
     if (t->d_redTables) (void)hipFree(t->d_redTables);
     if (t->contactPts) (void)hipFree(t->contactPts);
+    for (int m = 0; m < DARTK_MAX_MODELS; ++m)
+        if (t->d_damping[m]) (void)hipFree(t->d_damping[m]);
     if (t->poses) (void)hipFree(t->poses);
     if (t->slabs) (void)hipFree(t->slabs);
     delete t;
@@ -988,6 +1011,21 @@ int dartk_noobs_create_reduced(int nModels, const dartk_model_t *models, const d
     return DARTK_OK;
 }
 
+int dartk_noobs_set_damping(dartk_noobs_t h, int modelNum, const float *h_matrix, void *stream) {
+    NoObs *t = reinterpret_cast<NoObs *>(h);
+    DARTK_REQUIRE(t, "dartk_noobs_set_damping: null handle");
+    DARTK_REQUIRE(modelNum >= 0 && modelNum < t->h.nModels, "model %d out of range [0,%d)", modelNum, t->h.nModels);
+    if (!h_matrix) { t->dampingOn[modelNum] = false; return DARTK_OK; }
+    const size_t bytes = sizeof(float) * (size_t)t->h.dims[modelNum] * t->h.dims[modelNum];
+    if (!t->d_damping[modelNum]) DARTK_HIP(hipMalloc((void **)&t->d_damping[modelNum], bytes));
+    // a set-up call: the matrix may still be read by a solve in flight on another stream, and h_matrix is pageable
+    DARTK_HIP(hipDeviceSynchronize());
+    DARTK_HIP(hipMemcpyAsync(t->d_damping[modelNum], h_matrix, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    DARTK_HIP(hipStreamSynchronize(as_stream(stream)));
+    t->dampingOn[modelNum] = true;
+    return DARTK_OK;
+}
+
 int dartk_noobs_set_priors(dartk_noobs_t h, const dartk_contact_prior *h_priors, int nPriors, void *stream) {
     NoObs *t = reinterpret_cast<NoObs *>(h);
     DARTK_REQUIRE(t && (h_priors || nPriors == 0), "dartk_noobs_set_priors: null argument");
@@ -1074,6 +1112,7 @@ static int noobs_check_opts(NoObs *t, const dartk_noobs_options *o) {
 static void noobs_fill_args(NoObs *t, const dartk_noobs_options *o, NoObsSolveArgs &a) {
     memset(&a, 0, sizeof(a));
     for (int m = 0; m < o->nModels; ++m) { a.regularization[m] = o->regularization[m]; a.regularizationScaled[m] = o->regularizationScaled[m]; }
+    for (int m = 0; m < DARTK_MAX_MODELS; ++m) a.damping[m] = (m < o->nModels && t->dampingOn[m]) ? t->d_damping[m] : nullptr;
     for (int i = 0; i < o->nModels * o->nModels; ++i) a.lambda[i] = o->lambdaIntersection[i];
     a.numIterations = o->numIterations;
 }

@@ -59,6 +59,7 @@ class Tracker:
         self.opts.regularization, self.opts.regularizationScaled = [], []
         self.opts.distThreshold, self.opts.planeOffset, self.opts.planeNormal = [], [], []
         self.priors = []
+        self.damping = []     # per model: [dims, dims] damping matrix (getDampingMatrix), zero at first
         dev = torch.device("cuda", torch.cuda.current_device())
         self.prediction = torch.zeros((self.pred_height, self.pred_width, 4), dtype=torch.float32, device=dev)
         self.iteration_summaries = None
@@ -71,6 +72,20 @@ class Tracker:
     def clearPriors(self):
         self.priors = []
 
+    def getDampingMatrix(self, model_num):
+        """Tracker::getDampingMatrix (tracker.h:122): the [dims, dims] matrix added to the model's block of the normal equations
+        after the regularisation and the LM scaling (optimizer.cpp:702-703); modify it in place."""
+        return self.damping[model_num]
+
+    def _damping_dev(self, m, keep):
+        """device pointer of model m's damping matrix, None while it is zero"""
+        D = self.damping[m]
+        if not D.any():
+            return None
+        t = torch.from_numpy(np.ascontiguousarray(D, dtype=F)).to(self.prediction.device)
+        keep.append(t)
+        return device._ptr(t)
+
     def addModel(self, host_model, reduction=None, collision_cloud_density=1e5, cloud_seed=0):
         """Tracker::addModel (tracker.cpp:59-267): device mirror incl. the 64^3 observation SDF, collision cloud, pose."""
         m_id = len(self.models)
@@ -81,6 +96,7 @@ class Tracker:
         red = reduction or NullReduction(host_model.n_joints, lim[:, 0], lim[:, 1], host_model.joint_names)
         self.poses.append(Pose(red))
         rd = 6 + red.getReducedDimensions()
+        self.damping.append(np.zeros((rd, rd), dtype=F))      # _dampingMatrices.push_back(Zero(...)) (tracker.cpp:246-247)
         if red.isNull():
             self.red_dev.append(None)
         elif red.isParamMap():
@@ -163,6 +179,7 @@ class Tracker:
             for k in range(3):
                 c.planeNormal[k] = float(o.planeNormal[m][k])
             c.regularization, c.regularizationScaled = float(o.regularization[m]), float(o.regularizationScaled[m])
+            c.d_damping = self._damping_dev(m, keep)
         mo = _abi.MultiOptionsC()
         mo.numIterations, mo.nModels = int(o.numIterations), n
         mo.lambdaObsToMod, mo.lambdaModToObs = float(o.lambdaObsToMod), float(o.lambdaModToObs)
@@ -246,6 +263,7 @@ class Tracker:
             for k in range(3):
                 c.planeNormal[k] = float(o.planeNormal[m][k])
             c.regularization, c.regularizationScaled = float(o.regularization[m]), float(o.regularizationScaled[m])
+            c.d_damping = self._damping_dev(m, keep)
         mo = _abi.MultiOptionsC()
         mo.numIterations, mo.nModels = int(o.numIterations), n
         mo.lambdaObsToMod, mo.lambdaModToObs = float(o.lambdaObsToMod), float(o.lambdaModToObs)
@@ -325,7 +343,8 @@ class Tracker:
                 J = np.triu(J) + np.triu(J, 1).T                                   # make JTJ symmetric, :688-692
                 J[np.diag_indices(dims)] += F(o.regularization[m]) * F(1.0)        # :695
                 J[np.diag_indices(dims)] += F(o.regularizationScaled[m]) * J[np.diag_indices(dims)]     # :698-700
-                U[off:off + dims, off:off + dims] = np.triu(J)                     # :707-713 (damping matrices are zero)
+                J = (J + self.damping[m]).astype(F)                                # :702-703
+                U[off:off + dims, off:off + dims] = np.triu(J)                     # :707-713
                 JTe[off:off + dims] = eJ
                 info[it, m] = (eO2M, eM2O, eInt, counts[m], n_pred, 0, 0, 0)
             if it == 0 and debug:

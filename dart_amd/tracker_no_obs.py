@@ -132,6 +132,8 @@ class TrackerNoObs:
         self.T_mc = []          # per model, camera->model (Pose::getTransformCameraToModel)
         self.joints = []        # per model: the joints, or the REDUCED articulation of a model with a pose reduction
         self.reductions = []    # per model: None | LinearPoseReduction | ParamMapPoseReduction (pose.py)
+        self.damping = []       # per model: [dims, dims] damping matrix (getDampingMatrix), zero at first
+        self._damping_sig = {}
         self.priors: List[ContactPrior] = []
         self.point_priors: List[Point3D3DPrior] = []      # evaluated after the contact priors (device and oracle alike)
         self.opts = OptimizationOptions()
@@ -159,6 +161,8 @@ class TrackerNoObs:
         self.potentials.append(torch.ones(n * n, dtype=torch.int32, device=dev))
         self.T_mc.append(se3.identity())
         self.joints.append(np.zeros(host_model.n_joints if self.reductions[-1] is None else self.reductions[-1].getReducedDimensions(), dtype=F))
+        # _dampingMatrices.push_back(Zero(reducedDims, reducedDims)) (tracker_no_obs.cpp:214-215)
+        self.damping.append(np.zeros((6 + len(self.joints[-1]),) * 2, dtype=F))
         n_models = len(self.models)
         # option vectors grow with the models (tracker_no_obs.cpp:219-229)
         old = self.opts.lambdaIntersection
@@ -171,6 +175,11 @@ class TrackerNoObs:
         self.opts.regularizationScaled.append(self.opts.regularizationScaled[0] if self.opts.regularizationScaled else 1.0)
         self._handle = None
         return m_id
+
+    def getDampingMatrix(self, model_num):
+        """TrackerNoObs::getDampingMatrix (tracker_no_obs.h:73): the [dims, dims] matrix added to the model's block of the normal
+        equations (optimizer.cpp:895-896); modify it in place."""
+        return self.damping[model_num]
 
     def getNumModels(self):
         return len(self.models)
@@ -235,6 +244,7 @@ class TrackerNoObs:
         reds, keep = self.reductions_struct(_abi.ReductionC)
         check(lib().dartk_noobs_create_reduced(n, handles, reds, clouds, counts, pots, lam, arr, len(self.priors), self.max_batch, C.byref(h)))
         self._handle = h
+        self._damping_sig = {}
         self._terms_key = key
         self._priors_sig = self._sig()
         self._points_sig = None
@@ -278,6 +288,12 @@ class TrackerNoObs:
         return [(p.weight, tuple(p.contactPoint), p.contactThreshold, p.update_contact_point) for p in self.priors]
 
     def _sync_priors(self):
+        for m, D in enumerate(self.damping):        # damping matrices: uploaded when they change, dropped when zero again
+            sig = D.tobytes() if D.any() else None
+            if self._damping_sig.get(m) != sig:
+                Dc = np.ascontiguousarray(D, dtype=F)
+                check(lib().dartk_noobs_set_damping(self._handle, m, Dc.ctypes.data_as(C.POINTER(C.c_float)) if sig else None, device._stream()))
+                self._damping_sig[m] = sig
         psig = [p.sig() for p in self.point_priors]
         if getattr(self, "_points_sig", None) != psig and (psig or getattr(self, "_points_sig", None)):
             arr = priors_array(self.point_priors, _abi.PointPriorC)

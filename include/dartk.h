@@ -297,8 +297,8 @@ typedef struct dartk_noobs_s *dartk_noobs_t;
 /* TrackerNoObs state for one set of models (tracker_no_obs.cpp:58-235, 271-299): collision clouds (float4, xyz in the
  * owning SDF's frame, w = SDF number), intersection-potential matrices, contact priors, and a pose / partial-system
  * workspace for up to maxBatch independent candidates. Model m has model ID m. The intersection terms that exist
- * (lambdaIntersection > 0) are fixed here; their values may change per call. Damping matrices are zero
- * (tracker_no_obs.cpp:214-215). */
+ * (lambdaIntersection > 0) are fixed here; their values may change per call. Damping matrices start as zero
+ * (tracker_no_obs.cpp:214-215; dartk_noobs_set_damping). */
 int dartk_noobs_create(int nModels, const dartk_model_t *models, const float *const *d_collisionClouds,
                        const int32_t *nCloudPoints, const int32_t *const *d_potentialIntersection,
                        const float *h_lambdaIntersection, const dartk_contact_prior *h_priors, int nPriors, int maxBatch,
@@ -322,6 +322,10 @@ int dartk_noobs_create_reduced(int nModels, const dartk_model_t *models, const d
                                const int32_t *const *d_potentialIntersection, const float *h_lambdaIntersection,
                                const dartk_contact_prior *h_priors, int nPriors, int maxBatch, dartk_noobs_t *out);
 int dartk_noobs_destroy(dartk_noobs_t t);
+/* TrackerNoObs::getDampingMatrix (tracker_no_obs.h:73): the matrix OptimizerNoObs adds to model modelNum's block before the
+ * priors contribute (optimizer.cpp:895-896). h_matrix: [dims][dims] row-major, dims = the model's reduced dimensions
+ * (6 + joints, or 6 + redArtDims); NULL = zero again. Shared by all candidates of a batch. */
+int dartk_noobs_set_damping(dartk_noobs_t t, int modelNum, const float *h_matrix, void *stream);
 /* ContactPrior::setWeight / setContactThreshold / contact point resets (priors.h:66-67, grasp_analyzer.cpp:941-981) */
 int dartk_noobs_set_priors(dartk_noobs_t t, const dartk_contact_prior *h_priors, int nPriors, void *stream);
 /* Point3D3DPrior / Point2D3DPrior (src/optimization/priors.h:92-170; computeContribution point_3d_3d_prior.cpp:6-69,
@@ -380,6 +384,9 @@ typedef struct dartk_multi_model {
     dartk_da_point *d_pts;      /* association list, capacity width*height */
     float distThreshold, planeOffset, planeNormal[3];
     float regularization, regularizationScaled;
+    /* Tracker::getDampingMatrix (tracker.h:122; optimizer.cpp:702-703: added to the model's block after the regularisation and
+     * the LM scaling): [dims][dims] row-major, dims = 6 + redArtDims, device, or NULL (zero, the tracker's initial value) */
+    const float *d_damping;
 } dartk_multi_model;
 typedef struct dartk_multi_options {
     int32_t numIterations, nModels;

@@ -141,6 +141,10 @@ static int prior_param_offsets(const orc_contact_prior *priors, int nPriors, int
  * prior objects, contact_prior.cpp:212-219), or NULL */
 static float *g_contactOut = NULL;
 void orc_set_contact_out(float *out) { g_contactOut = out; }
+/* Tracker / TrackerNoObs::getDampingMatrix (tracker.h:122, tracker_no_obs.h:73): one [dims][dims] row-major matrix per model
+ * (NULL entries or a NULL list = zero, the trackers' initial value), used by both loops below until reset */
+static const float *const *g_damping = NULL;
+void orc_set_damping(const float *const *mats) { g_damping = mats; }
 static orc_contact_prior *priors_copy(const orc_contact_prior *priors, int nPriors) {
     orc_contact_prior *c = (orc_contact_prior *)malloc(sizeof(orc_contact_prior) * (size_t)(nPriors > 0 ? nPriors : 1));
     if (nPriors > 0) memcpy(c, priors, sizeof(orc_contact_prior) * (size_t)nPriors);
@@ -277,7 +281,9 @@ float orc_optimize_poses_noobs(const orc_model *const *models, float *const *T_m
             float *J = (float *)calloc((size_t)dims * dims, sizeof(float));
             float *sys = (float *)malloc(sizeof(float) * (size_t)sys_len(6 + models[m]->n_joints));
             eInt += noobs_intersection_terms(&c, models, T_mcs, m, o, clouds, nClouds, potentials, eJ, J, sys);
-            /* symmetrise, += damping (zero), scatter the upper triangle (optimizer.cpp:881-905) */
+            /* symmetrise, += damping, scatter the upper triangle (optimizer.cpp:881-905) */
+            if (g_damping && g_damping[m])
+                for (int i = 0; i < dims; ++i) for (int j = i; j < dims; ++j) J[i * dims + j] += g_damping[m][i * dims + j];
             for (int i = 0; i < dims; ++i) for (int j = i; j < dims; ++j)
                 if (J[i * dims + j] != 0) JTJ[(off + i) * sysN + off + j] = J[i * dims + j];
             for (int i = 0; i < dims; ++i) JTe[off + i] = eJ[i];
@@ -459,10 +465,12 @@ void orc_optimize_poses(const orc_model *const *models, float *const *T_mcs, flo
                 eInt = orc_unpack(eJ, J, dims, sys, o->lambdaIntersection[m + d * n], dims);
             }
             (void)fullDims;
-            /* symmetrise; += reg*I; A_ii += lm*A_ii; += damping (zero); scatter the upper triangle (:688-714) */
+            /* symmetrise; += reg*I; A_ii += lm*A_ii; += damping; scatter the upper triangle (:688-714) */
             for (int i = 0; i < dims; ++i) for (int j = 0; j < i; ++j) J[i * dims + j] = J[j * dims + i];
             for (int i = 0; i < dims; ++i) J[i * dims + i] += o->regularization[m] * 1.0f;
             for (int i = 0; i < dims; ++i) J[i * dims + i] += o->regularizationScaled[m] * J[i * dims + i];
+            if (g_damping && g_damping[m])
+                for (int i = 0; i < dims * dims; ++i) J[i] += g_damping[m][i];
             for (int i = 0; i < dims; ++i) for (int j = i; j < dims; ++j)
                 if (J[i * dims + j] != 0) JTJ[(off + i) * sysN + off + j] = J[i * dims + j];
             for (int i = 0; i < dims; ++i) JTe[off + i] = eJ[i];

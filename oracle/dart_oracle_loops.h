@@ -94,6 +94,9 @@ float orc_get_error_noobs(const orc_model *const *models, float *const *T_mcs, f
 /* orc_optimize_poses_noobs / orc_optimize_poses write the contact points of their priors after the last iteration here
  * ([nPriors][3]; priors with update_contact_point move, contact_prior.cpp:207-221). The pointer is kept; NULL clears it. */
 void orc_set_contact_out(float *out);
+/* damping matrices of the trackers (tracker.h:122, tracker_no_obs.h:73; optimizer.cpp:702-703, 895-896): [nModels] pointers to
+ * [dims][dims] row-major matrices, NULL entries / NULL list = zero; stays in force for both loops until reset */
+void orc_set_damping(const float *const *mats);
 
 #ifdef __cplusplus
 }

@@ -385,6 +385,23 @@ class contact_out:
         return False
 
 
+class damping_matrices:
+    """with damping_matrices([D0, None, ...]): both optimisation loops of the oracle add model m's [dims, dims] matrix to its
+    block (Tracker / TrackerNoObs::getDampingMatrix; optimizer.cpp:702-703, 895-896); None = zero."""
+
+    def __init__(self, mats):
+        self.keep = [None if m is None else np.ascontiguousarray(m, dtype=F) for m in mats]
+        self.arr = (fp * len(self.keep))(*[fp() if m is None else f(m) for m in self.keep])
+
+    def __enter__(self):
+        lib().orc_set_damping(self.arr)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_damping(None)
+        return False
+
+
 def project_to_sdf_surface(grid, point_grid, threshold=1e-5, max_iters=100):
     """orc_project_to_sdf_surface (sdf.cpp:6-23) on grid coordinates; returns the projected point."""
     p = c32(point_grid).copy()
@@ -488,8 +505,11 @@ def optimize_poses(tracker, vert, norm, T_mcs, arts, priors=()):
     h, w = vert.shape[:2]
     from dart_amd.tracker_no_obs import priors_array
     parr = priors_array(list(priors), OrcContactPrior)
-    lib().orc_optimize_poses(models, T_ptrs, a_ptrs, reds, C.byref(mo), f(c32(vert)), f(c32(norm)), w, h, c_ptrs, counts, p_ptrs,
-                             parr if len(priors) else None, len(priors), obs_ptrs, f(info), f(first))
+    # the tracker's damping matrices (Tracker::getDampingMatrix), None while zero
+    mats = [D if D.any() else None for D in getattr(tracker, "damping", [None] * n)] if getattr(tracker, "damping", None) else [None] * n
+    with damping_matrices(mats):
+        lib().orc_optimize_poses(models, T_ptrs, a_ptrs, reds, C.byref(mo), f(c32(vert)), f(c32(norm)), w, h, c_ptrs, counts, p_ptrs,
+                                 parr if len(priors) else None, len(priors), obs_ptrs, f(info), f(first))
     return T_keep, [a_keep[m][:len(arts[m])] for m in range(n)], info, first
 
 
