@@ -200,6 +200,10 @@ def _load(path):
         "dartk_ne_mod2obs_reduced": [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp],
         "dartk_ne_mod2obs_parammap": [C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp],
         "dartk_error_mod2obs": [vp, C.c_int, C.c_int, vp, c_float_p, vp],
+        "dartk_mod2obs_debug_maps": [vp, C.c_int, C.c_int, vp, c_float_p, C.c_int, C.c_float, vp, vp, vp, vp],
+        "dartk_init_debug_intersection_error": [vp, C.c_int, vp],
+        "dartk_debug_self_intersection_error": [vp, C.c_int, vp, vp, vp, vp],
+        "dartk_debug_intersection_error": [vp, C.c_int, c_float_p, vp, vp, vp, vp],
         "dartk_ne_self_intersection": [vp, C.c_int, C.c_int, vp, vp, vp, vp],
         "dartk_ne_self_intersection_reduced": [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp],
         "dartk_ne_self_intersection_parammap": [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp],

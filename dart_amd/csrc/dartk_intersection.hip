@@ -158,6 +158,34 @@ __global__ void count_inter_kernel(const float4 *__restrict__ sites, int nSites,
     if ((threadIdx.x & 63) == 0 && mask) atomicAdd(n, __popcll(mask));
 }
 
+// the terms' optional debugError output (intersection.cu:131-133 self: = residual^2; :433-435 pairwise: += residual^2; sites
+// without a collision are left as they are -- NaN after initDebugIntersectionError, :303-313)
+__global__ void debug_error_self_kernel(const float4 *__restrict__ sites, int nSites, ModelView m, const int *__restrict__ pot,
+                                        float *__restrict__ debugError) {
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= nSites) return;
+    const float4 v = sites[index];
+    const int srcGrid = (int)roundf(v.w);
+    const f3 vm = se3_apply_w(m.T_mf + 12 * m.sdfFrame[srcGrid], v.x, v.y, v.z, 1.0f);
+    const Collision c = first_collision(m, m.T_fm, vm, pot, srcGrid);
+    if (c.hit) debugError[index] = c.residual * c.residual;
+}
+__global__ void debug_error_inter_kernel(const float4 *__restrict__ sites, int nSites, ModelView src, ModelView dst,
+                                         const float *__restrict__ T_ds, float *__restrict__ debugError) {
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= nSites) return;
+    const float4 v = sites[index];
+    const int srcGrid = (int)roundf(v.w);
+    const f3 vsm = se3_apply_w(src.T_mf + 12 * src.sdfFrame[srcGrid], v.x, v.y, v.z, 1.0f);
+    const f3 vdm = se3_apply_w(T_ds, vsm.x, vsm.y, vsm.z, 1.0f);
+    const Collision c = first_collision(dst, dst.T_fm, vdm, nullptr, 0);
+    if (c.hit) debugError[index] += c.residual * c.residual;
+}
+__global__ void debug_error_init_kernel(float *__restrict__ debugError, int nSites) {
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index < nSites) debugError[index] = __int_as_float(0x7fc00000);
+}
+
 static int check_sites(const Model *m, int nSites) {
     DARTK_REQUIRE(m != nullptr, "null model");
     DARTK_REQUIRE(nSites >= 0, "negative site count");
@@ -391,6 +419,44 @@ int dartk_count_self_intersections(const float *d_sites, int nSites, dartk_model
     DARTK_HIP(hipGetLastError());
     DARTK_HIP(hipMemcpyAsync(h_count, ws->counters, sizeof(int), hipMemcpyDeviceToHost, st));
     DARTK_HIP(hipStreamSynchronize(st));
+    return DARTK_OK;
+}
+
+int dartk_init_debug_intersection_error(float *d_debugError, int nSites, void *stream) {
+    DARTK_REQUIRE((d_debugError || nSites == 0) && nSites >= 0, "dartk_init_debug_intersection_error: bad argument");
+    if (nSites > 0)
+        hipLaunchKernelGGL(debug_error_init_kernel, dim3((nSites + 255) / 256), dim3(256), 0, as_stream(stream), d_debugError, nSites);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
+int dartk_debug_self_intersection_error(const float *d_sites, int nSites, dartk_model_t h, const int32_t *d_pot,
+                                        float *d_debugError, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE((d_sites || nSites == 0) && d_pot && mod && (d_debugError || nSites == 0) && nSites >= 0,
+                  "dartk_debug_self_intersection_error: bad argument");
+    if (nSites > 0)
+        hipLaunchKernelGGL(debug_error_self_kernel, dim3((nSites + 127) / 128), dim3(128), 0, as_stream(stream), (const float4 *)d_sites, nSites,
+                           mod->v, d_pot, d_debugError);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
+int dartk_debug_intersection_error(const float *d_sites, int nSites, const float *h_T_ds, dartk_model_t hs, dartk_model_t hd,
+                                   float *d_debugError, void *stream) {
+    Model *src = reinterpret_cast<Model *>(hs), *dst = reinterpret_cast<Model *>(hd);
+    DARTK_REQUIRE((d_sites || nSites == 0) && h_T_ds && src && dst && (d_debugError || nSites == 0) && nSites >= 0,
+                  "dartk_debug_intersection_error: bad argument");
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    DARTK_HIP(hipMemcpyAsync(ws->sysScratch + 64, h_T_ds, 12 * sizeof(float), hipMemcpyHostToDevice, st));
+    DARTK_HIP(hipStreamSynchronize(st));
+    if (nSites > 0)
+        hipLaunchKernelGGL(debug_error_inter_kernel, dim3((nSites + 127) / 128), dim3(128), 0, st, (const float4 *)d_sites, nSites, src->v, dst->v,
+                           ws->sysScratch + 64, d_debugError);
+    DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
 

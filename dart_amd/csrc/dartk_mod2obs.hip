@@ -787,6 +787,41 @@ error_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, ModelView m, dou
     if (threadIdx.x == 0) blockSums[blockIdx.x] = red[0];
 }
 
+// The optional debug maps of normEqnsModToObs / Truncated / Reduced / ParamMap (modToObs.cu:47-49,65,74,82; truncated :145-147,
+// 168,178,186): per prediction pixel the label, the residual and the obs-SDF gradient, with the reference's clearing rule (label
+// and residual only cleared by model 0, the gradient map always). A kernel of its own: the maps are visualisation aids
+// (optimization.h debugModToObs*), the normal-equation kernels stay free of their stores.
+template <bool TRUNC>
+__global__ void __launch_bounds__(256)
+mod2obs_debug_maps_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, ModelView m, const float *__restrict__ T_gc_in,
+                          float truncationDist, int *__restrict__ dbgDA, float *__restrict__ dbgErr, float4 *__restrict__ dbgNorm) {
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= nPix) return;
+    if (dbgDA && modelNum == 0) dbgDA[index] = -1;
+    if (dbgErr && modelNum == 0) dbgErr[index] = __int_as_float(0x7fc00000);
+    if (dbgNorm) dbgNorm[index] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 pc = pred[index];
+    if (pc.z == 0) return;
+    float T_gc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T_gc[i] = T_gc_in[i];
+    const SdfDev obs = m.obs;
+    f3 p3; p3.x = pc.x; p3.y = pc.y; p3.z = pc.z;
+    const f3 pm = se3_apply(T_gc, p3);
+    const f3 pg = grid_coords(obs, pm);
+    if (!in_bounds_grad_interp(obs, pg)) return;
+    const float residual = grid_value(m.obsData, obs.dimx, obs.dimy, pg) * obs.res;
+    if (TRUNC && (residual >= truncationDist || residual < 0)) return;
+    if (dbgErr) dbgErr[index] = residual;
+    const int label = (int)roundf(pc.w);
+    if ((label >> 16) != modelNum) return;
+    if (dbgDA) dbgDA[index] = label;
+    if (dbgNorm) {
+        const f3 g = grid_gradient(m.obsData, obs.dimx, obs.dimy, pg);
+        dbgNorm[index] = make_float4(g.x, g.y, g.z, 1.0f);
+    }
+}
+
 DARTK_COUNTER_ACCESS(mod2obs)
 
 }  // namespace dartk
@@ -916,6 +951,31 @@ int dartk_ne_mod2obs_parammap(int dims, int redDims, const int32_t *d_map, const
     DARTK_REQUIRE(mod && d_pred && d_result && d_num && d_map, "dartk_ne_mod2obs_parammap: null argument");
     DARTK_REQUIRE(redDims >= 6 && redDims <= dims, "redDims %d must be in [6,%d]", redDims, dims);
     return launch_ne_mod2obs<2, false>(dims, redDims, d_pred, width, height, mod, mod->v.T_mc, 0.f, nullptr, d_map, d_result, d_num, false, as_stream(stream));
+}
+
+int dartk_mod2obs_debug_maps(const float *d_pred, int width, int height, dartk_model_t h, const float *h_T_gc, int truncated,
+                             float truncationDistance, int32_t *d_dbgDA, float *d_dbgErr, float *d_dbgNorm, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_pred && width > 0 && height > 0, "dartk_mod2obs_debug_maps: bad argument");
+    DARTK_REQUIRE(mod->obsVoxels > 0, "model has no observation SDF");
+    if (!d_dbgDA && !d_dbgErr && !d_dbgNorm) return DARTK_OK;
+    hipStream_t st = as_stream(stream);
+    const float *d_T = mod->v.T_mc;          // the Truncated / Reduced / ParamMap wrappers use the model's own transform
+    if (h_T_gc) {
+        float *up = nullptr;
+        int rc = upload_T(h_T_gc, &up, st);
+        if (rc) return rc;
+        d_T = up;
+    }
+    const int nPix = width * height;
+    if (truncated)
+        hipLaunchKernelGGL(mod2obs_debug_maps_kernel<true>, dim3((nPix + 255) / 256), dim3(256), 0, st, (const float4 *)d_pred, nPix,
+                           mod->v.modelId, mod->v, d_T, truncationDistance, d_dbgDA, d_dbgErr, (float4 *)d_dbgNorm);
+    else
+        hipLaunchKernelGGL(mod2obs_debug_maps_kernel<false>, dim3((nPix + 255) / 256), dim3(256), 0, st, (const float4 *)d_pred, nPix,
+                           mod->v.modelId, mod->v, d_T, 0.0f, d_dbgDA, d_dbgErr, (float4 *)d_dbgNorm);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
 }
 
 int dartk_error_mod2obs(const float *d_pred, int width, int height, dartk_model_t h, float *h_error, void *stream) {

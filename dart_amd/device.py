@@ -295,6 +295,33 @@ def norm_eqns_intersection(sites, src, dst, T_ds, T_sd, reduction=None, result=N
     return result
 
 
+def mod_to_obs_debug_maps(prediction, model, T_gc=None, truncation=None, da=None, err=None, norm=None):
+    """The debug maps of normEqnsModToObs{,Truncated,Reduced,ParamMap} (OptimizationOptions::debugModToObsDA / Err / Norm): int32
+    [H*W] labels, float [H*W] residuals, float [H*W,4] gradients, updated in place (created zero-filled when not given)."""
+    h, w = prediction.shape[:2]
+    dev = prediction.device
+    da = torch.zeros(h * w, dtype=torch.int32, device=dev) if da is None else da
+    err = torch.zeros(h * w, dtype=torch.float32, device=dev) if err is None else err
+    norm = torch.zeros((h * w, 4), dtype=torch.float32, device=dev) if norm is None else norm
+    T = None if T_gc is None else np.ascontiguousarray(T_gc, dtype=F).reshape(12)
+    check(lib().dartk_mod2obs_debug_maps(_ptr(prediction), w, h, model.handle, None if T is None else _abi.fptr(T),
+                                         0 if truncation is None else 1, 0.0 if truncation is None else float(truncation),
+                                         _ptr(da), _ptr(err), _ptr(norm), _stream()))
+    return da, err, norm
+
+
+def debug_intersection_error(sites, model, potential, pairs=()):
+    """_dDebugIntersectionError of one model's collision cloud (optimizer.cpp:646-682): NaN, then the self term's residual^2, then
+    += residual^2 of every pairwise term in `pairs` = [(T_ds, dst model), ...]."""
+    out = torch.empty(sites.shape[0], dtype=torch.float32, device=sites.device)
+    check(lib().dartk_init_debug_intersection_error(_ptr(out), sites.shape[0], _stream()))
+    check(lib().dartk_debug_self_intersection_error(_ptr(sites), sites.shape[0], model.handle, _ptr(potential), _ptr(out), _stream()))
+    for T_ds, dst in pairs:
+        a = np.ascontiguousarray(T_ds, dtype=F).reshape(12)
+        check(lib().dartk_debug_intersection_error(_ptr(sites), sites.shape[0], _abi.fptr(a), model.handle, dst.handle, _ptr(out), _stream()))
+    return out
+
+
 def count_self_intersections(sites, model, potential):
     c = np.zeros(1, dtype=np.int32)
     check(lib().dartk_count_self_intersections(_ptr(sites), sites.shape[0], model.handle, _ptr(potential), _abi.iptr(c), _stream()))

@@ -190,6 +190,16 @@ int dartk_ne_mod2obs_reduced(int dims, int redDims, const float *d_dtheta_dalpha
 int dartk_ne_mod2obs_parammap(int dims, int redDims, const int32_t *d_mapping, const float *d_pred, int width,
                               int height, dartk_model_t m, float *d_result, int32_t *d_numPredictions,
                               void *stream);
+/* The optional debug maps of normEqnsModToObs / Truncated / Reduced / ParamMap (modToObs.h:26-28,39-41,52-54,64-66; written at
+ * modToObs.cu:47-49,65,74,82 and :145-147,168,178,186; the optimizer passes them when OptimizationOptions::debugModToObsDA / Err /
+ * Norm are set, optimizer.cpp:296-324), by a kernel of their own so that the normal-equation kernels carry no stores for them:
+ * d_dbgDA [height*width] label of the pixel's prediction when it is this model's (cleared to -1 only by the model with ID 0, as
+ * there), d_dbgErr [height*width] its residual (cleared to NaN only by model 0), d_dbgNorm [height*width][4] the observation
+ * SDF's gradient, w = 1 (always cleared to 0). Any of the three may be NULL. h_T_gc: the transform normEqnsModToObs is given, or
+ * NULL for the model's own camera->model transform (what the other three wrappers use). truncated != 0: the Truncated
+ * kernel's rule (pixels outside [0, truncationDistance) leave no residual). */
+int dartk_mod2obs_debug_maps(const float *d_pred, int width, int height, dartk_model_t m, const float *h_T_gc, int truncated,
+                             float truncationDistance, int32_t *d_dbgDA, float *d_dbgErr, float *d_dbgNorm, void *stream);
 /* errorModToObs, modToObs.cu:1030-1048: returns 0.5*sum err^2 in *h_error */
 int dartk_error_mod2obs(const float *d_pred, int width, int height, dartk_model_t m, float *h_error,
                         void *stream);
@@ -213,6 +223,16 @@ int dartk_ne_intersection_reduced(const float *d_sites, int nSites, int fullDims
 int dartk_ne_intersection_parammap(const float *d_sites, int nSites, int fullDims, int redDims,
                                    const float *h_T_ds, const float *h_T_sd, dartk_model_t src, dartk_model_t dst,
                                    const int32_t *d_mapping, float *d_result, void *stream);
+/* The terms' optional debugError output (intersection.h:26,54,78-79; the optimizer passes one array over all models' collision
+ * clouds when OptimizationOptions::debugIntersectionErr is set, optimizer.cpp:646-682): initDebugIntersectionError sets NaN
+ * (intersection.cu:303-313, 988-995), a colliding site of the self term gets residual^2 (:131-133), of a pairwise term
+ * += residual^2 (:433-435: NaN stays NaN unless the self term wrote the site first); other sites are left as they are.
+ * Kernels of their own, same collision test as the normal-equation kernels. */
+int dartk_init_debug_intersection_error(float *d_debugError, int nSites, void *stream);
+int dartk_debug_self_intersection_error(const float *d_sites, int nSites, dartk_model_t m,
+                                        const int32_t *d_potentialIntersection, float *d_debugError, void *stream);
+int dartk_debug_intersection_error(const float *d_sites, int nSites, const float *h_T_ds, dartk_model_t src,
+                                   dartk_model_t dst, float *d_debugError, void *stream);
 /* countSelfIntersections / countIntersections, intersection.cu:715-763 (blocking; return the count) */
 int dartk_count_self_intersections(const float *d_sites, int nSites, dartk_model_t m,
                                    const int32_t *d_potentialIntersection, int32_t *h_count, void *stream);

@@ -982,6 +982,79 @@ int orc_count_intersections(const float *sites, int nSites, const float *T_ds, c
     return n;
 }
 
+/* The kernels' optional debug outputs. modToObs.cu:47-49,65,74,82 (gpu_normEqnsModToObs; the Reduced / ParamMap kernels write
+ * the same at :249-286, :350-387) and :145-147,168,178,186 (Truncated; truncationDist < 0 here = the plain kernels). Any map may be
+ * NULL. dbgNorm: [height*width][4]. */
+void orc_mod2obs_debug_maps(const float *pred, int width, int height, int modelNum, const float *T_gc, const orc_grid *obsSdf,
+                            float truncationDist, int32_t *dbgDA, float *dbgErr, float *dbgNorm) {
+    for (int index = 0; index < width * height; ++index) {
+        if (dbgDA && modelNum == 0) dbgDA[index] = -1;
+        if (dbgErr && modelNum == 0) dbgErr[index] = NAN;
+        if (dbgNorm) dbgNorm[4 * index] = dbgNorm[4 * index + 1] = dbgNorm[4 * index + 2] = dbgNorm[4 * index + 3] = 0;
+        const float *pc = pred + 4 * index;
+        if (pc[2] == 0) continue;
+        float pm[4], pg[3];
+        se3_apply3(T_gc, pc, pm); pm[3] = 1;
+        orc_grid_coords(obsSdf, pm, pg);
+        if (!orc_grid_in_bounds_gradient_interp(obsSdf, pg)) continue;
+        const float residual = orc_grid_value_interp(obsSdf, pg) * obsSdf->resolution;
+        if (truncationDist >= 0 && (residual >= truncationDist || residual < 0)) continue;
+        if (dbgErr) dbgErr[index] = residual;
+        const int label = (int)round(pc[3]);
+        if ((label >> 16) != modelNum) continue;
+        if (dbgDA) dbgDA[index] = label;
+        if (dbgNorm) {
+            float gm[3];
+            orc_grid_gradient_interp(obsSdf, pg, gm);
+            dbgNorm[4 * index] = gm[0]; dbgNorm[4 * index + 1] = gm[1]; dbgNorm[4 * index + 2] = gm[2]; dbgNorm[4 * index + 3] = 1;
+        }
+    }
+}
+
+/* intersection.cu:303-313 (NaN everywhere), :131-133 (self term: a colliding site gets residual^2), :433-435 (pairwise term:
+ * += residual^2); sites without a collision keep what they held */
+void orc_init_debug_intersection_error(float *debugError, int nSites) {
+    for (int i = 0; i < nSites; ++i) debugError[i] = NAN;
+}
+void orc_debug_self_intersection_error(const float *sites, int nSites, const orc_model *m, const float *T_fm, const float *T_mf,
+                                       const int32_t *pot, float *debugError) {
+    for (int index = 0; index < nSites; ++index) {
+        float vs[4] = {sites[4 * index], sites[4 * index + 1], sites[4 * index + 2], 1};
+        const int srcGrid = (int)round(sites[4 * index + 3]);
+        float vm[4];
+        se3_apply4(T_mf + 12 * m->sdf_frame[srcGrid], vs, vm);
+        for (int dstGrid = 0; dstGrid < m->n_sdfs; ++dstGrid) {
+            if (!pot[dstGrid + srcGrid * m->n_sdfs]) continue;
+            float vd[4], vg[3];
+            se3_apply4(T_fm + 12 * m->sdf_frame[dstGrid], vm, vd);
+            const orc_grid sdf = model_sdf(m, dstGrid);
+            orc_grid_coords(&sdf, vd, vg);
+            if (!orc_grid_in_bounds_gradient_interp(&sdf, vg)) continue;
+            const float residual = orc_grid_value_interp(&sdf, vg) * sdf.resolution;
+            if (residual < 0) { debugError[index] = residual * residual; break; }
+        }
+    }
+}
+void orc_debug_intersection_error(const float *sites, int nSites, const float *T_ds, const orc_model *src, const float *T_mf_src,
+                                  const orc_model *dst, const float *T_fm_dst, float *debugError) {
+    for (int index = 0; index < nSites; ++index) {
+        float vs[4] = {sites[4 * index], sites[4 * index + 1], sites[4 * index + 2], 1};
+        const int srcGrid = (int)round(sites[4 * index + 3]);
+        float vsm[4], vdm[4];
+        se3_apply4(T_mf_src + 12 * src->sdf_frame[srcGrid], vs, vsm);
+        se3_apply4(T_ds, vsm, vdm);
+        for (int dstGrid = 0; dstGrid < dst->n_sdfs; ++dstGrid) {
+            float vd[4], vg[3];
+            se3_apply4(T_fm_dst + 12 * dst->sdf_frame[dstGrid], vdm, vd);
+            const orc_grid sdf = model_sdf(dst, dstGrid);
+            orc_grid_coords(&sdf, vd, vg);
+            if (!orc_grid_in_bounds_gradient_interp(&sdf, vg)) continue;
+            const float residual = orc_grid_value_interp(&sdf, vg) * sdf.resolution;
+            if (residual < 0) { debugError[index] += residual * residual; break; }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * assembly + solve
  * ---------------------------------------------------------------------------------------------- */

@@ -149,6 +149,14 @@ int orc_ne_intersection(const float *sites, int nSites, const float *T_ds, const
                         const orc_model *dst, const float *T_fm_dst, const float *T_mf_dst, int reduction,
                         int redDims, const float *dtheta_dalpha, const int32_t *mapping, float *result);
 /* gpu_selfIntersectionCount :11-64 / gpu_intersectionCount :315-365 */
+/* the kernels' optional debug outputs (modToObs.cu:47-82,145-186; intersection.cu:131-133,303-313,433-435) */
+void orc_mod2obs_debug_maps(const float *pred, int width, int height, int modelNum, const float *T_gc, const orc_grid *obsSdf,
+                            float truncationDist, int32_t *dbgDA, float *dbgErr, float *dbgNorm);
+void orc_init_debug_intersection_error(float *debugError, int nSites);
+void orc_debug_self_intersection_error(const float *sites, int nSites, const orc_model *m, const float *T_fm, const float *T_mf,
+                                       const int32_t *pot, float *debugError);
+void orc_debug_intersection_error(const float *sites, int nSites, const float *T_ds, const orc_model *src, const float *T_mf_src,
+                                  const orc_model *dst, const float *T_fm_dst, float *debugError);
 int orc_count_self_intersections(const float *sites, int nSites, const orc_model *m, const float *T_fm,
                                  const float *T_mf, const int32_t *potentialIntersection);
 int orc_count_intersections(const float *sites, int nSites, const float *T_ds, const orc_model *src,

@@ -255,6 +255,28 @@ def ne_mod2obs(pred, om, T_gc, T_fm, T_mf, obs_grid, truncation=None, reduction=
     return res, n
 
 
+def mod2obs_debug_maps(pred, model_num, T_gc, obs_grid, truncation=None, da=None, err=None, norm=None):
+    """orc_mod2obs_debug_maps: updates (and returns) the three debug maps, created with the reference's buffers' zero fill."""
+    h, w = pred.shape[:2]
+    da = np.zeros(h * w, dtype=np.int32) if da is None else da
+    err = np.zeros(h * w, dtype=F) if err is None else err
+    norm = np.zeros((h * w, 4), dtype=F) if norm is None else norm
+    lib().orc_mod2obs_debug_maps(f(c32(pred)), w, h, int(model_num), f(c32(T_gc)), C.byref(obs_grid),
+                                 C.c_float(-1.0 if truncation is None else truncation), i(da), f(err), f(norm))
+    return da, err, norm
+
+
+def debug_intersection_error(sites_self, om, T_fm, T_mf, pot, pairs=()):
+    """initDebugIntersectionError, then the self term's and every (T_ds, dst, T_fm_dst) pairwise term's debugError writes"""
+    out = np.zeros(len(sites_self), dtype=F)
+    lib().orc_init_debug_intersection_error(f(out), len(out))
+    pot = np.ascontiguousarray(pot, dtype=np.int32)
+    lib().orc_debug_self_intersection_error(f(c32(sites_self)), len(out), om.ref, f(c32(T_fm)), f(c32(T_mf)), i(pot), f(out))
+    for T_ds, dst, T_fm_d in pairs:
+        lib().orc_debug_intersection_error(f(c32(sites_self)), len(out), f(c32(T_ds)), om.ref, f(c32(T_mf)), dst.ref, f(c32(T_fm_d)), f(out))
+    return out
+
+
 def error_mod2obs(pred, obs_grid):
     return float(lib().orc_error_mod2obs(f(c32(pred)), pred.shape[1], pred.shape[0], C.byref(obs_grid)))
 
