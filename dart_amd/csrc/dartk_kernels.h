@@ -54,7 +54,10 @@ int gn_launch_raycast_replay_at(float flx, float fly, float ppx, float ppy, int 
                                 float *d_prediction, size_t bufOffset, hipStream_t st);
 int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float ppy, int width, int height, int nModels,
                                         Model *const *mods, const size_t *bufOffsets, float *d_prediction, const float *d_obs, int ow,
-                                        int oh, hipStream_t st);
+                                        int oh, hipStream_t st, int *d_hitCount = nullptr);
+// batches: the replay can leave each frame's hits back to back at the start of its map region (d_hitCount[frame * counts stride]
+// of them) instead of the map; gn_ne_mod2obs_any then walks the list (d_nItems = the same counters)
+bool gn_replay_hit_lists(int nModels, Model *const *mods);
 int gn_launch_raycast(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                       float *d_prediction, hipStream_t st);
 int gn_launch_cull(float *d_pred, int pw, int ph, const float *d_obs, int ow, int oh, hipStream_t st);
@@ -81,7 +84,8 @@ int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr
 int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void *d_args, int *d_last, hipStream_t st,
                           const int *d_validIdx = nullptr, const int *d_nValid = nullptr);
 int gn_ne_mod2obs_any(int red, int fullDims, int redDims, const float *d_pred, int width, int height, Model *mod,
-                      const float *d_T_gc, const float *d_A, const int *d_map, float *d_result, int *d_num, hipStream_t st);
+                      const float *d_T_gc, const float *d_A, const int *d_map, float *d_result, int *d_num, hipStream_t st,
+                      const int *d_nItems = nullptr);
 int gn_ne_self_any(int red, const float *d_sites, int nSites, int fullDims, int redDims, Model *mod, const float *d_A,
                    const int *d_map, const int *d_pot, float *d_result, hipStream_t st);
 int gn_ne_inter_any(int red, const float *d_sites, int nSites, int fullDims, int redDims, Model *src, Model *dst,

@@ -163,7 +163,7 @@ raycast_replay_multi_kernel(float flx, float fly, float ppx, float ppy, int widt
 __global__ void __launch_bounds__(256)
 raycast_replay_multi_rows_kernel(float flx, float fly, float ppx, float ppy, int width, int height, ReplayMultiArgs a,
                                  const float *__restrict__ rayBuf, float4 *__restrict__ prediction, const float4 *__restrict__ obs, int ow,
-                                 int oh, FrameBatch fb) {
+                                 int oh, FrameBatch fb, int *__restrict__ hitCount) {
     extern __shared__ float lds[];
     const int frame = blockIdx.y;
     rayBuf += (size_t)frame * fb.trace;
@@ -183,25 +183,42 @@ raycast_replay_multi_rows_kernel(float flx, float fly, float ppx, float ppy, int
         __syncthreads();
     }
     const int nChunks = (nPix + 255) / 256;
+    if (hitCount) hitCount += (size_t)frame * fb.counts;
     for (int chunk = blockIdx.x; chunk < nChunks; chunk += gridDim.x) {
         const int index = chunk * 256 + threadIdx.x;
-        if (index >= nPix) continue;
-        const int x = index % width, y = index / width;
+        const bool inMap = index < nPix;
+        const int x = inMap ? index % width : 0, y = inMap ? index / width : 0;
         // model 0 starts the map. The reference leaves x, y of a pixel without a hit as they were; nothing reads them (every
         // consumer tests z first), and this kernel only ever writes the loop's own scratch map, so they are not fetched
         float4 pr = make_float4(0.f, 0.f, 0.f, -1.f);
-        int off = 0;
-        for (int mi = 0; mi < a.n; ++mi) {
-            const int n = a.m[mi].nSdfs;
-            float closestT = 10000;
-            replay_pixel(pr, closestT, x, y, n, reinterpret_cast<const int *>(lds + off), mi, 0, n, lds + off + 4 * n + 1,
-                         reinterpret_cast<const float2 *>(rayBuf + a.off[mi]), flx, fly, ppx, ppy);
-            off += 28 * n + 1;
+        if (inMap) {
+            int off = 0;
+            for (int mi = 0; mi < a.n; ++mi) {
+                const int n = a.m[mi].nSdfs;
+                float closestT = 10000;
+                replay_pixel(pr, closestT, x, y, n, reinterpret_cast<const int *>(lds + off), mi, 0, n, lds + off + 4 * n + 1,
+                             reinterpret_cast<const float2 *>(rayBuf + a.off[mi]), flx, fly, ppx, ppy);
+                off += 28 * n + 1;
+            }
+            const int ox = x * ow / width, oy = y * oh / height;
+            const int oi = ox + oy * ow;
+            if (pr.z != 0 && (obs[oi].w <= 0 || obs[oi + 1].w <= 0 || obs[oi + ow].w <= 0 || obs[oi + ow + 1].w <= 0)) pr.z = 0;
         }
-        const int ox = x * ow / width, oy = y * oh / height;
-        const int oi = ox + oy * ow;
-        if (pr.z != 0 && (obs[oi].w <= 0 || obs[oi + 1].w <= 0 || obs[oi + ow].w <= 0 || obs[oi + ow + 1].w <= 0)) pr.z = 0;
-        prediction[index] = pr;
+        if (!hitCount) {
+            if (inMap) prediction[index] = pr;
+            continue;
+        }
+        // hit-list form: the frame's map region holds its hits back to back instead (a few percent of the pixels), appended per
+        // wave; the consumers walk hitCount entries. Neither the pixels without a hit nor their positions are written.
+        const bool hit = inMap && pr.z != 0;
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(hitCount, __popcll(mask));
+            base = __shfl(base, 0);
+            if (hit) prediction[base + __popcll(mask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = pr;
+        }
     }
 }
 
@@ -417,7 +434,8 @@ template <int PPT, int RED, bool TRUNC, bool REPLAY = false>
 __global__ void __launch_bounds__(NE_BLOCK)
 ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, ModelView m_in, const float *__restrict__ T_gc_in,
                   float truncationDist, int redDims, const float *__restrict__ dtheta_dalpha, const int *__restrict__ mapping,
-                  float *__restrict__ slabs, int *__restrict__ numPredictions, ReplayArgs ra, FrameBatch fb, int tgcStride) {
+                  float *__restrict__ slabs, int *__restrict__ numPredictions, ReplayArgs ra, FrameBatch fb, int tgcStride,
+                  const int *__restrict__ nItems) {
     extern __shared__ float lds[];
 #ifdef DARTK_STAMPS
     unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -428,6 +446,8 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
     pred += (size_t)blockIdx.y * fb.pred;
     T_gc_in += (size_t)blockIdx.y * tgcStride;
     numPredictions += (size_t)blockIdx.y * fb.counts;
+    // hit-list form (batches): `pred` holds the frame's hits back to back, nItems[frame] of them (raycast_replay_multi_rows_kernel)
+    if (nItems) nPix = nItems[(size_t)blockIdx.y * fb.counts];
     const int fullDims = 6 + m.nJoints;
     const int d = RED ? redDims : fullDims;
     const int ld = row_len(d, false);
@@ -574,7 +594,8 @@ size_t ne_mod2obs_lds_bytes(const ModelView &m, int d, int red) {
 template <int RED, bool TRUNC>
 static int launch_ne_mod2obs_kernel(int fullDims, int redDims, const float *d_pred, int width, int height,
                                     const ModelView &m, const float *d_T_gc, float trunc, const float *d_A,
-                                    const int *d_map, float *slabs, int nBlocks, int *d_num, hipStream_t st) {
+                                    const int *d_map, float *slabs, int nBlocks, int *d_num, hipStream_t st,
+                                    const int *d_nItems = nullptr) {
     const int d = RED ? redDims : fullDims;
     const int S = sys_size(d);
     const int nPix = width * height;
@@ -589,7 +610,7 @@ static int launch_ne_mod2obs_kernel(int fullDims, int redDims, const float *d_pr
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
         hipLaunchKernelGGL(kfn, dim3(nBlocks, fb.n), dim3(NE_BLOCK), ldsBytes, st, pred, nPix, m.modelId, m, d_T_gc, trunc, \
-                           redDims, d_A, d_map, slabs, d_num, ReplayArgs{}, fb, tgcStride);                     \
+                           redDims, d_A, d_map, slabs, d_num, ReplayArgs{}, fb, tgcStride, d_nItems);           \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_M2O(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_M2O(6);
@@ -602,7 +623,7 @@ static int launch_ne_mod2obs_kernel(int fullDims, int redDims, const float *d_pr
 template <int RED, bool TRUNC>
 static int launch_ne_mod2obs(int fullDims, int redDims, const float *d_pred, int width, int height, Model *mod,
                              const float *d_T_gc, float trunc, const float *d_A, const int *d_map, float *d_result,
-                             int *d_num, bool zeroCounter, hipStream_t st) {
+                             int *d_num, bool zeroCounter, hipStream_t st, const int *d_nItems = nullptr) {
     const ModelView &m = mod->v;
     const int d = RED ? redDims : fullDims;
     DARTK_REQUIRE(fullDims == 6 + m.nJoints, "dims %d does not match the model's 6+%d", fullDims, m.nJoints);
@@ -615,23 +636,25 @@ static int launch_ne_mod2obs(int fullDims, int redDims, const float *d_pred, int
     if (rc) return rc;
     const int nPix = width * height;
     const int nTiles = (nPix + NE_BLOCK - 1) / NE_BLOCK;
-    const int cap = cur_batch().n > 1 ? 128 : kMaxPartialBlocks;    // a batch fills the chip with its frames
+    // a batch fills the chip with its frames; a frame's hit list is a few percent of its map
+    const int cap = d_nItems ? 32 : cur_batch().n > 1 ? 128 : kMaxPartialBlocks;
     const int nBlocks = nTiles < cap ? nTiles : cap;
     rc = ensure_partials(ws, (size_t)cur_batch().n * nBlocks * S);
     if (rc) return rc;
     if (zeroCounter) DARTK_HIP(hipMemsetAsync(d_num, 0, sizeof(int), st));
     rc = launch_ne_mod2obs_kernel<RED, TRUNC>(fullDims, redDims, d_pred, width, height, m, d_T_gc, trunc, d_A, d_map,
-                                              lane_partials(ws), nBlocks, d_num, st);
+                                              lane_partials(ws), nBlocks, d_num, st, d_nItems);
     if (rc) return rc;
     return launch_reduce_slabs(lane_partials(ws), nBlocks, S, d_result, 1, st);
 }
 
 // whole term (kernel + reduction into d_result) for the device-resident multi-model loop; red: 0 full, 1 linear, 2 map
 int gn_ne_mod2obs_any(int red, int fullDims, int redDims, const float *d_pred, int width, int height, Model *mod,
-                      const float *d_T_gc, const float *d_A, const int *d_map, float *d_result, int *d_num, hipStream_t st) {
-    if (red == 1) return launch_ne_mod2obs<1, false>(fullDims, redDims, d_pred, width, height, mod, d_T_gc, 0.f, d_A, nullptr, d_result, d_num, false, st);
-    if (red == 2) return launch_ne_mod2obs<2, false>(fullDims, redDims, d_pred, width, height, mod, d_T_gc, 0.f, nullptr, d_map, d_result, d_num, false, st);
-    return launch_ne_mod2obs<0, false>(fullDims, fullDims, d_pred, width, height, mod, d_T_gc, 0.f, nullptr, nullptr, d_result, d_num, false, st);
+                      const float *d_T_gc, const float *d_A, const int *d_map, float *d_result, int *d_num, hipStream_t st,
+                      const int *d_nItems) {
+    if (red == 1) return launch_ne_mod2obs<1, false>(fullDims, redDims, d_pred, width, height, mod, d_T_gc, 0.f, d_A, nullptr, d_result, d_num, false, st, d_nItems);
+    if (red == 2) return launch_ne_mod2obs<2, false>(fullDims, redDims, d_pred, width, height, mod, d_T_gc, 0.f, nullptr, d_map, d_result, d_num, false, st, d_nItems);
+    return launch_ne_mod2obs<0, false>(fullDims, fullDims, d_pred, width, height, mod, d_T_gc, 0.f, nullptr, nullptr, d_result, d_num, false, st, d_nItems);
 }
 
 // entry points for the device-resident Gauss-Newton loop (dartk_gn.hip)
@@ -662,7 +685,7 @@ int gn_launch_raycast_trace_at(float flx, float fly, float ppx, float ppy, int w
 }
 int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float ppy, int width, int height, int nModels,
                                         Model *const *mods, const size_t *bufOffsets, float *d_prediction, const float *d_obs, int ow,
-                                        int oh, hipStream_t st) {
+                                        int oh, hipStream_t st, int *d_hitCount) {
     Workspace *ws;
     int rc = get_workspace(&ws);
     if (rc) return rc;
@@ -682,12 +705,21 @@ int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float p
         int perFrame = (env ? atoi(env) : 2048) / cur_batch().n;
         perFrame = perFrame < 1 ? 1 : (perFrame > nChunks ? nChunks : perFrame);
         hipLaunchKernelGGL(raycast_replay_multi_rows_kernel, dim3(perFrame, cur_batch().n), dim3(256), ldsFloats * sizeof(float), st, flx, fly,
-                           ppx, ppy, width, height, a, (const float *)ws->rayBuf, (float4 *)d_prediction, (const float4 *)d_obs, ow, oh, cur_batch());
-    } else
+                           ppx, ppy, width, height, a, (const float *)ws->rayBuf, (float4 *)d_prediction, (const float4 *)d_obs, ow, oh, cur_batch(),
+                           d_hitCount);
+    } else {
+        DARTK_REQUIRE(!d_hitCount, "the hit-list form of the replay needs the batch kernel (gn_replay_hit_lists)");
         hipLaunchKernelGGL(raycast_replay_multi_kernel, dim3((unsigned)nChunks, cur_batch().n), dim3(256), 0, st, flx, fly, ppx, ppy, width, height,
                            a, (const float *)ws->rayBuf, (float4 *)d_prediction, (const float4 *)d_obs, ow, oh, cur_batch());
+    }
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
+}
+// whether gn_launch_raycast_replay_cull_multi would take the batch kernel for these models (the one that can emit hit lists)
+bool gn_replay_hit_lists(int nModels, Model *const *mods) {
+    size_t ldsFloats = 0;
+    for (int m = 0; m < nModels; ++m) ldsFloats += 28 * (size_t)mods[m]->v.nSdfs + 1;
+    return cur_batch().n > 1 && ldsFloats * sizeof(float) <= 64 * 1024 && getenv("DARTK_NO_HIT_LISTS") == nullptr;
 }
 int gn_launch_raycast_replay_at(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                                 float *d_prediction, size_t bufOffset, hipStream_t st) {
@@ -735,7 +767,7 @@ int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
         hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_prediction, nPix, m.modelId, m, d_T_gc, 0.f, \
-                           d, nullptr, nullptr, slabs, d_num, ra, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0}, 0);                   \
+                           d, nullptr, nullptr, slabs, d_num, ra, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0}, 0, (const int *)nullptr); \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_RM2O(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_RM2O(6);

@@ -579,15 +579,18 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
                 DARTK_HIP(hipEventRecord(ws->evTrace, stC));
                 DARTK_HIP(hipStreamWaitEvent(st, ws->evTrace, 0));      // after this stream's own trace, which takes as long
             }
-            rc = gn_launch_raycast_replay_cull_multi(o->predFl[0], o->predFl[1], ppx, ppy, o->predWidth, o->predHeight, n, mods, traceOff,
-                                                     d_prediction, d_vert, width, height, st);
-            if (rc) return rc;
+            // a batch keeps no prediction maps for the caller: the replay leaves each frame's hits as a list (a few percent of the
+            // map) and the mod->obs terms walk the list; the hit counter of a frame sits in the last slot of its prediction counters
+            int *d_hits = (batch && n < DARTK_MAX_MODELS && gn_replay_hit_lists(n, mods)) ? d_countB + (DARTK_MAX_MODELS - 1) : nullptr;
             DARTK_HIP(hipMemsetAsync(d_countB, 0, (batch ? (size_t)DARTK_MAX_MODELS * nFrames : (size_t)n) * sizeof(int), st));
+            rc = gn_launch_raycast_replay_cull_multi(o->predFl[0], o->predFl[1], ppx, ppy, o->predWidth, o->predHeight, n, mods, traceOff,
+                                                     d_prediction, d_vert, width, height, st, d_hits);
+            if (rc) return rc;
             for (int m = 0; m < n; ++m) {   // reduced wrappers use the model's current T_mc, the full one T_obsSdf_c (modToObs.cu:851-988 vs :713-780)
                 const MultiSolveModel &s = h.m[m];
                 ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
                 rc = gn_ne_mod2obs_any(s.redType, 6 + mods[m]->v.nJoints, s.dims, d_prediction, o->predWidth, o->predHeight, mods[m],
-                                       s.redType == 0 ? T_obs[m] : mods[m]->v.T_mc, mm[m].d_A, mm[m].d_map, sysB[m], d_countB + m, st);
+                                       s.redType == 0 ? T_obs[m] : mods[m]->v.T_mc, mm[m].d_A, mm[m].d_map, sysB[m], d_countB + m, st, d_hits);
                 if (rc) return rc;
             }
         }
