@@ -225,7 +225,8 @@ static int launch_self(const float *d_sites, int nSites, int fullDims, int redDi
         hipLaunchKernelGGL(kfn, dim3(nBlocks, fb.n), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, m, d_pot, \
                            redDims, d_A, d_map, lane_partials(ws));                                                  \
     } while (0)
-    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_SELF(3);
+    if (S <= NE_BLOCK) DARTK_LAUNCH_SELF(1);      // a small system: one output per thread, no idle accumulator slots
+    else if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_SELF(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_SELF(6);
     else DARTK_LAUNCH_SELF(20);
 #undef DARTK_LAUNCH_SELF
@@ -286,7 +287,8 @@ static int launch_inter_dev(const float *d_sites, int nSites, int fullDims, int 
         hipLaunchKernelGGL(kfn, dim3(nBlocks, fb.n), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, ms, md, \
                            d_T_ds_sd, redDims, d_A, d_map, lane_partials(ws), fb.tab);                               \
     } while (0)
-    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_INTER(3);
+    if (S <= NE_BLOCK) DARTK_LAUNCH_INTER(1);      // a small system: one output per thread, no idle accumulator slots
+    else if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_INTER(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_INTER(6);
     else DARTK_LAUNCH_INTER(20);
 #undef DARTK_LAUNCH_INTER
@@ -339,7 +341,8 @@ int gn_launch_ne_self(const float *d_sites, int nSites, const ModelView &m, cons
         hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, m, d_pot, \
                            fullDims, nullptr, nullptr, slabs);                                                  \
     } while (0)
-    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_SELF(3);
+    if (S <= NE_BLOCK) DARTK_LAUNCH_SELF(1);      // a small system: one output per thread, no idle accumulator slots
+    else if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_SELF(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_SELF(6);
     else DARTK_LAUNCH_SELF(20);
 #undef DARTK_LAUNCH_SELF

@@ -182,6 +182,26 @@ raycast_replay_multi_rows_kernel(float flx, float fly, float ppx, float ppy, int
         }
         __syncthreads();
     }
+    // the tile rectangle that holds every SDF's rectangle of every model: pixels outside it (most of a frame) cannot have a
+    // trace record, and a wave whose 64 pixels all lie outside skips the per-SDF walk altogether
+    __shared__ int sUnion[4];
+    if (threadIdx.x == 0) {
+        int x0 = 1 << 30, y0 = 1 << 30, x1 = -1, y1 = -1, off = 0;
+        for (int mi = 0; mi < a.n; ++mi) {
+            const int n = a.m[mi].nSdfs;
+            const int *sR = reinterpret_cast<const int *>(lds + off);
+            for (int s = 0; s < n; ++s) {
+                const int rw = sR[2 * n + s], cnt = sR[3 * n + s + 1] - sR[3 * n + s];
+                if (rw <= 0 || cnt <= 0) continue;
+                x0 = min(x0, sR[s]); y0 = min(y0, sR[n + s]);
+                x1 = max(x1, sR[s] + rw - 1); y1 = max(y1, sR[n + s] + (cnt + rw - 1) / rw - 1);
+            }
+            off += 28 * n + 1;
+        }
+        sUnion[0] = x0; sUnion[1] = y0; sUnion[2] = x1; sUnion[3] = y1;
+    }
+    __syncthreads();
+    const int ux0 = sUnion[0], uy0 = sUnion[1], ux1 = sUnion[2], uy1 = sUnion[3];
     const int nChunks = (nPix + 255) / 256;
     if (hitCount) hitCount += (size_t)frame * fb.counts;
     for (int chunk = blockIdx.x; chunk < nChunks; chunk += gridDim.x) {
@@ -191,7 +211,7 @@ raycast_replay_multi_rows_kernel(float flx, float fly, float ppx, float ppy, int
         // model 0 starts the map. The reference leaves x, y of a pixel without a hit as they were; nothing reads them (every
         // consumer tests z first), and this kernel only ever writes the loop's own scratch map, so they are not fetched
         float4 pr = make_float4(0.f, 0.f, 0.f, -1.f);
-        if (inMap) {
+        if (inMap && (x >> 3) >= ux0 && (x >> 3) <= ux1 && (y >> 3) >= uy0 && (y >> 3) <= uy1) {
             int off = 0;
             for (int mi = 0; mi < a.n; ++mi) {
                 const int n = a.m[mi].nSdfs;
@@ -612,7 +632,8 @@ static int launch_ne_mod2obs_kernel(int fullDims, int redDims, const float *d_pr
         hipLaunchKernelGGL(kfn, dim3(nBlocks, fb.n), dim3(NE_BLOCK), ldsBytes, st, pred, nPix, m.modelId, m, d_T_gc, trunc, \
                            redDims, d_A, d_map, slabs, d_num, ReplayArgs{}, fb, tgcStride, d_nItems);           \
     } while (0)
-    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_M2O(3);
+    if (S <= NE_BLOCK) DARTK_LAUNCH_M2O(1);      // a small system: one output per thread, no idle accumulator slots
+    else if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_M2O(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_M2O(6);
     else DARTK_LAUNCH_M2O(20);
 #undef DARTK_LAUNCH_M2O

@@ -257,7 +257,8 @@ static int launch_ne_obs2mod(int fullDims, int redDims, const float *d_vert, Mod
         hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, nElements, m,         \
                            huberDelta, redDims, d_A, d_map, lane_partials(ws), (const int *)nullptr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0}); \
     } while (0)
-    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_NE(3);
+    if (S <= NE_BLOCK) DARTK_LAUNCH_NE(1);      // a small system: one output per thread, no idle accumulator slots
+    else if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_NE(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_NE(6);
     else DARTK_LAUNCH_NE(20);
 #undef DARTK_LAUNCH_NE
@@ -295,7 +296,8 @@ static int launch_ne_obs2mod_dev(int fullDims, int redDims, const float *d_vert,
         hipLaunchKernelGGL(kfn, dim3(nBlocks, fb.n), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, maxElements, m, \
                            huberDelta, redDims, d_A, d_map, lane_partials(ws), d_count, fb);                         \
     } while (0)
-    if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_NE(3);
+    if (S <= NE_BLOCK) DARTK_LAUNCH_NE(1);      // a small system: one output per thread, no idle accumulator slots
+    else if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_NE(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_NE(6);
     else DARTK_LAUNCH_NE(20);
 #undef DARTK_LAUNCH_NE
