@@ -507,13 +507,14 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
 
     // association argument block (pose arrays are updated in place, so once per call)
     void *d_assocArgs = nullptr;
+    size_t assocStageBytes = 0;
     if (useA) {
         float thr[DARTK_MAX_MODELS], po[DARTK_MAX_MODELS], pn[3 * DARTK_MAX_MODELS];
         for (int m = 0; m < n; ++m) {
             thr[m] = mm[m].distThreshold; po[m] = mm[m].planeOffset;
             for (int k = 0; k < 3; ++k) pn[3 * m + k] = mm[m].planeNormal[k];
         }
-        rc = gn_assoc_multi_prepare(n, mods, thr, po, pn, ptsList, &d_assocArgs, st);
+        rc = gn_assoc_multi_prepare(n, mods, thr, po, pn, ptsList, &d_assocArgs, st, &assocStageBytes);
         if (rc) return rc;
     }
     // The observation is fixed for the call: its valid pixels (a few per cent of a 1280x720 map around a hand) are listed once
@@ -598,7 +599,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         if (useA) {
             {
                 ProfScope ps(DARTK_PROF_OTHER, stA);
-                rc = gn_assoc_multi_launch(d_vert, nPix, n, d_assocArgs, d_countA, stA, d_validIdx, d_nValid);
+                rc = gn_assoc_multi_launch(d_vert, nPix, n, d_assocArgs, d_countA, stA, d_validIdx, d_nValid, assocStageBytes);
                 if (rc) return rc;
             }
             for (int m = 0; m < n; ++m) {

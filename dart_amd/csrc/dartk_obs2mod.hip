@@ -71,14 +71,40 @@ struct MultiArgs {
     dartk_da_point *pts[DARTK_MAX_MODELS];
 };
 
-template <bool DBG>
+// words of LDS per model in the staged form: T_mc | T_fm[nFrames] | SDF -> frame | SDF headers
+__host__ __device__ inline int assoc_stage_words(const ModelView &m) {
+    return 12 + 12 * m.nFrames + m.nSdfs + (int)(sizeof(SdfDev) / 4) * m.nSdfs;
+}
+
+// STAGED (the loops' launches: a chip-sized grid whose workgroups stride over the valid-pixel list): every model's transforms,
+// SDF -> frame table and SDF headers are copied to LDS once per workgroup; the per-(pixel, SDF) loop then reads them there instead
+// of through two dependent scalar loads per SDF (frame index, then its transform) and a header fetch from memory.
+template <bool DBG, bool STAGED = false>
 __global__ void __launch_bounds__(256)
 assoc_multi_kernel(const float4 *__restrict__ vert, int nPix, const MultiArgs *__restrict__ args,
                    int *__restrict__ lastElement, int *__restrict__ dbgDA, float *__restrict__ dbgErr, FrameBatch fb,
                    const int *__restrict__ validIdx, const int *__restrict__ nValid) {
+    extern __shared__ float lds[];
     const int frame = blockIdx.y;                    // frame of a batch (0 otherwise)
     vert += (size_t)frame * fb.vert;
     lastElement += (size_t)frame * fb.counts;
+    if (STAGED) {
+        int off = 0;
+        const int nm = args->nModels;
+        for (int mi = 0; mi < nm; ++mi) {
+            const ModelView &m = args->m[mi];
+            const size_t po = (size_t)frame * (size_t)m.poseStride;
+            const int nT = 12 * m.nFrames, nS = m.nSdfs, nH = (int)(sizeof(SdfDev) / 4) * nS;
+            float *p = lds + off;
+            for (int i = threadIdx.x; i < 12 + nT; i += blockDim.x) p[i] = i < 12 ? m.T_mc[po + i] : m.T_fm[po + i - 12];
+            int *pi = reinterpret_cast<int *>(p + 12 + nT);
+            for (int i = threadIdx.x; i < nS; i += blockDim.x) pi[i] = m.sdfFrame[i];
+            const int *src = reinterpret_cast<const int *>(m.sdfs);
+            for (int i = threadIdx.x; i < nH; i += blockDim.x) pi[nS + i] = src[i];
+            off += assoc_stage_words(m);
+        }
+        __syncthreads();
+    }
     // with a list of the frame's valid pixels (gn_valid_pixels) the workgroups stride over the list instead of the map: the
     // launch then needs only as many workgroups as fill the chip, not one per 256 pixels of which most would find nothing
     const int nItems = validIdx ? nValid[frame] : nPix;
@@ -95,20 +121,25 @@ assoc_multi_kernel(const float4 *__restrict__ vert, int nPix, const MultiArgs *_
         const float4 xc = vert[index];
         if (xc.w > 0) {
             const int nModels = args->nModels;
+            int stageOff = 0;
             for (int mi = 0; mi < nModels; ++mi) {
                 const ModelView &m = args->m[mi];
                 const size_t po = (size_t)frame * (size_t)m.poseStride;
-                const float *__restrict__ T_mc = m.T_mc + po;
+                const float *sM = lds + stageOff;                           // STAGED: this model's block
+                stageOff += STAGED ? assoc_stage_words(m) : 0;
+                const float *T_mc = STAGED ? sM : m.T_mc + po;
                 const f3 xm = se3_apply_w(T_mc, xc.x, xc.y, xc.z, xc.w);
                 f3 pn; pn.x = args->pn[mi][0]; pn.y = args->pn[mi][1]; pn.z = args->pn[mi][2];
                 if (!(dot(xm, pn) >= args->planeOffset[mi])) continue;
                 const float thr = args->distThr[mi];
                 const int slot = keep_slot(thr);
-                const float *__restrict__ T_fm = m.T_fm + po;
+                const float *T_fm = STAGED ? sM + 12 : m.T_fm + po;
+                const int *sFrame = STAGED ? reinterpret_cast<const int *>(sM + 12 + 12 * m.nFrames) : m.sdfFrame;
+                const SdfDev *sdfTab = STAGED ? reinterpret_cast<const SdfDev *>(sFrame + m.nSdfs) : m.sdfs;
                 for (int g = 0; g < m.nSdfs; ++g) {
-                    const int f = m.sdfFrame[g];
+                    const int f = sFrame[g];
                     const f3 xf = se3_apply_w(T_fm + 12 * f, xm.x, xm.y, xm.z, xc.w);
-                    const SdfDev &s = m.sdfs[g];
+                    const SdfDev &s = sdfTab[g];
                     const f3 xg = grid_coords(s, xf);
                     if (!in_bounds_grad_interp(s, xg) || !in_keep_box(s, slot, xg)) continue;
                     const float d = sdf_value<CNT_ASSOC>(m.grids, s, xg) * s.res;
@@ -377,7 +408,12 @@ static int launch_ne_obs2mod_noalloc(int dims, const float *d_vert, Model *mod, 
 // multi-model association for the device-resident loop: the argument block is uploaded once per optimizePoses call
 // (the ModelViews point at pose arrays that are updated in place), then one launch per iteration
 int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr, const float *planeOffset, const float *pn3,
-                           dartk_da_point *const *pts, void **d_args_out, hipStream_t st) {
+                           dartk_da_point *const *pts, void **d_args_out, hipStream_t st, size_t *stageBytes) {
+    if (stageBytes) {
+        size_t w = 0;
+        for (int i = 0; i < nModels; ++i) w += (size_t)assoc_stage_words(mods[i]->v);
+        *stageBytes = w * sizeof(float);
+    }
     ArgSlot slot;           // pinned staging: the upload needs no host wait (the slot is released as soon as the copy is enqueued)
     int rc = arg_ring_acquire(sizeof(MultiArgs), &slot);
     if (rc) return rc;
@@ -400,13 +436,18 @@ int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr
     return DARTK_OK;
 }
 int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void *d_args, int *d_last, hipStream_t st,
-                          const int *d_validIdx, const int *d_nValid) {
+                          const int *d_validIdx, const int *d_nValid, size_t stageBytes) {
     const FrameBatch fb = cur_batch();
     DARTK_HIP(hipMemsetAsync(d_last, 0, (fb.n > 1 ? (size_t)fb.n * fb.counts : (size_t)nModels) * sizeof(int), st));
     int wgs = (nPix + 255) / 256;
     if (d_validIdx) { const int cap = fb.n > 1 ? (8192 / fb.n > 16 ? 8192 / fb.n : 16) : 2048; if (wgs > cap) wgs = cap; }
-    hipLaunchKernelGGL(assoc_multi_kernel<false>, dim3(wgs, fb.n), dim3(256), 0, st, (const float4 *)d_vert, nPix,
-                       (const MultiArgs *)d_args, d_last, nullptr, nullptr, fb, d_validIdx, d_nValid);
+    // with a valid-pixel list the grid is chip-sized and each workgroup walks many pixels: the tables are worth staging
+    if (d_validIdx && stageBytes > 0 && stageBytes <= 64 * 1024 && !getenv("DARTK_ASSOC_UNSTAGED"))
+        hipLaunchKernelGGL((assoc_multi_kernel<false, true>), dim3(wgs, fb.n), dim3(256), stageBytes, st, (const float4 *)d_vert, nPix,
+                           (const MultiArgs *)d_args, d_last, nullptr, nullptr, fb, d_validIdx, d_nValid);
+    else
+        hipLaunchKernelGGL((assoc_multi_kernel<false, false>), dim3(wgs, fb.n), dim3(256), 0, st, (const float4 *)d_vert, nPix,
+                           (const MultiArgs *)d_args, d_last, nullptr, nullptr, fb, d_validIdx, d_nValid);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
