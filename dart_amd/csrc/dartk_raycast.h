@@ -137,6 +137,113 @@ __device__ __forceinline__ void replay_tables_to_global(const ModelView &m, floa
     for (int i = threadIdx.x; i < 28 * n + 1; i += blockDim.x) out[i] = scratch[i];
 }
 
+// One ray of one SDF: the set-up (ray in the SDF's frame, intersectBox, keep-box cull) and -- MARCH_NOW -- the march. `s`, `x`, `y`
+// may differ per lane (the packed form below marches rays of several tiles and SDFs in one wave); with a wave-uniform `s` the
+// tables are read through the scalar cache as before. wantMarch: the ray has to be marched (the set-up alone decides that);
+// det / hit: the record ({3e38, 0} = no crossing).
+template <bool MARCH_NOW>
+__device__ __forceinline__ void trace_one_ray(const ModelView &m, int s, int x, int y, float flx, float fly, float ppx, float ppy, int slot,
+                                              float levelSet, bool &wantMarch, float &detOut, float &hitOut) {
+    float T_fc[12];
+    {
+        const int f = m.sdfFrame[s];
+        float T_fm[12], T_mc[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { T_fm[i] = m.T_fm[12 * f + i]; T_mc[i] = m.T_mc[i]; }
+        se3_mul(T_fm, T_mc, T_fc);              // T_fms[f]*T_mc
+    }
+    const RayGeom g = ray_in_frame(T_fc, x, y, flx, fly, ppx, ppy);
+    const f3 of = g.of, dn = g.dn;
+    const SdfDev &sdf = m.sdfs[s];
+    const float smaxx = sdf.ox + sdf.res * (float)(unsigned)sdf.dimx;
+    const float smaxy = sdf.oy + sdf.res * (float)(unsigned)sdf.dimy;
+    const float smaxz = sdf.oz + sdf.res * (float)(unsigned)sdf.dimz;
+    const float hix = (float)((unsigned)sdf.dimx - 2u), hiy = (float)((unsigned)sdf.dimy - 2u), hiz = (float)((unsigned)sdf.dimz - 2u);
+    float t0, t1;   // intersectBox, raycast.cu:11-35
+    const float ix = 1.0f / dn.x, iy = 1.0f / dn.y, iz = 1.0f / dn.z;
+    {
+        const float bx = ix * (sdf.ox - of.x), by = iy * (sdf.oy - of.y), bz = iz * (sdf.oz - of.z);
+        const float tx = ix * (smaxx - of.x), ty = iy * (smaxy - of.y), tz = iz * (smaxz - of.z);
+        t0 = fmaxf(fmaxf(fminf(tx, bx), fminf(ty, by)), fminf(tz, bz));
+        t1 = fminf(fminf(fmaxf(tx, bx), fmaxf(ty, by)), fmaxf(tz, bz));
+    }
+    float det = 3.0e38f, hit = 0.0f;
+    bool march = t1 > t0;
+    // A crossing needs a sample with value <= levelSet, i.e. a sample inside the SDF's keep box for that level (SdfDev;
+    // samples are clamped to [1, dim-2], so a box side that reaches the clamp planes extends to infinity): a ray that
+    // misses the box is not marched at all -- it could only have ended with "no crossing". Most rays of a tile miss the
+    // few-centimetre link inside its 10 cm padding. The slabs are tested in frame units with intersectBox's reciprocals (the box
+    // carries a margin of 0.05 voxel, five orders of magnitude above the rounding of either form): no division of its own --
+    // this test runs for every ray of every tile and is most of what a ray that is not marched costs.
+    if (march && slot >= 0) {
+        const float o3[3] = {sdf.ox, sdf.oy, sdf.oz}, of3[3] = {of.x, of.y, of.z}, d3[3] = {dn.x, dn.y, dn.z}, i3[3] = {ix, iy, iz};
+        const float top[3] = {hix, hiy, hiz};
+        float tin = -3.0e38f, tout = 3.0e38f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = sdf.keepLo[slot][a], hi = sdf.keepHi[slot][a];
+            if (!(lo <= hi)) { tin = 1.0f; tout = 0.0f; break; }        // nothing at or below the level in this SDF
+            const bool openLo = lo <= 1.0f, openHi = hi >= top[a];
+            const float Lf = o3[a] + sdf.res * (lo - 0.05f), Hf = o3[a] + sdf.res * (hi + 0.05f);
+            float ta = (Lf - of3[a]) * i3[a], tb = (Hf - of3[a]) * i3[a];
+            if (openLo) ta = (d3[a] > 0) ? -3.0e38f : 3.0e38f;
+            if (openHi) tb = (d3[a] > 0) ? 3.0e38f : -3.0e38f;
+            if (d3[a] == 0.0f) {                                            // parallel to the slab: inside or never
+                const bool inside = (openLo || of3[a] >= Lf) && (openHi || of3[a] <= Hf);
+                ta = inside ? -3.0e38f : 3.0e38f; tb = inside ? 3.0e38f : -3.0e38f;
+            }
+            tin = fmaxf(tin, fminf(ta, tb));
+            tout = fminf(tout, fmaxf(ta, tb));
+        }
+        march = tin <= tout;
+    }
+    wantMarch = march;
+    if (MARCH_NOW && march) {
+        const float *data = m.grids + sdf.dataOff;
+        // header fields in registers for the march (the compiler does not hoist loads through the SdfDev reference)
+        const float res = sdf.res, rcp = sdf.rcpRes, ox = sdf.ox, oy = sdf.oy, oz = sdf.oz;
+        const bool exactDiv = sdf.divExact != 0;
+        const int dimx = sdf.dimx, dimy = sdf.dimy, nbx = sdf.nbx, nby = sdf.nby;
+        auto eval = [&](float tt) -> float {
+            f3 xf, xg;
+            xf.x = dn.x * tt + of.x; xf.y = dn.y * tt + of.y; xf.z = dn.z * tt + of.z;
+            const float dx = xf.x - ox, dy = xf.y - oy, dz = xf.z - oz;
+            if (exactDiv) { xg.x = div_exact(dx, res, rcp); xg.y = div_exact(dy, res, rcp); xg.z = div_exact(dz, res, rcp); }
+            else { xg.x = dx / res; xg.y = dy / res; xg.z = dz / res; }
+            xg.x = fmaxf(1.0f, fminf(xg.x, hix));
+            xg.y = fmaxf(1.0f, fminf(xg.y, hiy));
+            xg.z = fmaxf(1.0f, fminf(xg.z, hiz));
+            return sdf_lookup<CNT_RAYCAST>(data, dimx, dimy, nbx, nby, xg) * res;
+        };
+        float sdfValPrev = eval(t0);
+        float tPrev = t0;
+#ifdef DARTK_STAMPS
+        int steps = 0;
+#endif
+        const float minStep = res / 10;
+        while (t0 < t1 && t0 < 10000.0f) {      // 10000 = the reference's initial closestT
+            const float sdfVal = eval(t0);
+            if (sdfValPrev > levelSet && sdfVal <= levelSet) {
+                det = t0;
+                hit = (t0 - tPrev) * (levelSet - sdfValPrev) / (sdfVal - sdfValPrev) + tPrev;
+                break;      // the reference's loop ends here too: closestT = hit <= t0 < the next t0
+            }
+            sdfValPrev = sdfVal;
+            tPrev = t0;
+            t0 += fmaxf(minStep, fabsf(sdfVal));
+#ifdef DARTK_STAMPS
+            ++steps;
+#endif
+        }
+#ifdef DARTK_STAMPS
+        atomicMax(&g_rayMaxSteps, steps);
+        atomicAdd(&g_raySteps, (unsigned long long)steps);
+        atomicAdd(&g_rayMarched, 1ull);
+#endif
+    }
+    detOut = det; hitOut = hit;
+}
+
 // the tasks firstTask, firstTask + taskStride, ... of one wave (sR: the table of stage_ray_rects, already staged and synced)
 __device__ __forceinline__ void raycast_trace_tasks(int firstTask, int taskStride, const int *sR, float flx, float fly, float ppx, float ppy,
                                                     int width, int height, const ModelView &m, float2 *__restrict__ trace, float levelSet) {
@@ -151,101 +258,8 @@ __device__ __forceinline__ void raycast_trace_tasks(int firstTask, int taskStrid
         const int x = (sR[s] + local % rw) * 8 + (lane & 7);
         const int y = (sR[n + s] + local / rw) * 8 + (lane >> 3);
         if (x >= width || y >= height) continue;
-        float T_fc[12];
-        {
-            const int f = m.sdfFrame[s];
-            float T_fm[12], T_mc[12];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) { T_fm[i] = m.T_fm[12 * f + i]; T_mc[i] = m.T_mc[i]; }
-            se3_mul(T_fm, T_mc, T_fc);              // T_fms[f]*T_mc
-        }
-        const RayGeom g = ray_in_frame(T_fc, x, y, flx, fly, ppx, ppy);
-        const f3 of = g.of, dn = g.dn;
-        const SdfDev &sdf = m.sdfs[s];
-        const float smaxx = sdf.ox + sdf.res * (float)(unsigned)sdf.dimx;
-        const float smaxy = sdf.oy + sdf.res * (float)(unsigned)sdf.dimy;
-        const float smaxz = sdf.oz + sdf.res * (float)(unsigned)sdf.dimz;
-        const float hix = (float)((unsigned)sdf.dimx - 2u), hiy = (float)((unsigned)sdf.dimy - 2u), hiz = (float)((unsigned)sdf.dimz - 2u);
-        float t0, t1;   // intersectBox, raycast.cu:11-35
-        {
-            const float ix = 1.0f / dn.x, iy = 1.0f / dn.y, iz = 1.0f / dn.z;
-            const float bx = ix * (sdf.ox - of.x), by = iy * (sdf.oy - of.y), bz = iz * (sdf.oz - of.z);
-            const float tx = ix * (smaxx - of.x), ty = iy * (smaxy - of.y), tz = iz * (smaxz - of.z);
-            t0 = fmaxf(fmaxf(fminf(tx, bx), fminf(ty, by)), fminf(tz, bz));
-            t1 = fminf(fminf(fmaxf(tx, bx), fmaxf(ty, by)), fmaxf(tz, bz));
-        }
-        float det = 3.0e38f, hit = 0.0f;
-        bool march = t1 > t0;
-        // A crossing needs a sample with value <= levelSet, i.e. a sample inside the SDF's keep box for that level (SdfDev;
-        // samples are clamped to [1, dim-2], so a box side that reaches the clamp planes extends to infinity): a ray that
-        // misses the box is not marched at all -- it could only have ended with "no crossing". Most rays of a tile miss the
-        // few-centimetre link inside its 10 cm padding.
-        if (march && slot >= 0) {
-            const float g0[3] = {(of.x - sdf.ox) / sdf.res, (of.y - sdf.oy) / sdf.res, (of.z - sdf.oz) / sdf.res};
-            const float gd[3] = {dn.x / sdf.res, dn.y / sdf.res, dn.z / sdf.res};
-            const float top[3] = {hix, hiy, hiz};
-            float tin = -3.0e38f, tout = 3.0e38f;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float lo = sdf.keepLo[slot][a], hi = sdf.keepHi[slot][a];
-                if (!(lo <= hi)) { tin = 1.0f; tout = 0.0f; break; }        // nothing at or below the level in this SDF
-                const bool openLo = lo <= 1.0f, openHi = hi >= top[a];
-                const float inv = 1.0f / gd[a];
-                float ta = ((lo - 0.05f) - g0[a]) * inv, tb = ((hi + 0.05f) - g0[a]) * inv;
-                if (openLo) ta = (gd[a] > 0) ? -3.0e38f : 3.0e38f;
-                if (openHi) tb = (gd[a] > 0) ? 3.0e38f : -3.0e38f;
-                if (gd[a] == 0.0f) {                                            // parallel to the slab: inside or never
-                    const bool inside = (openLo || g0[a] >= lo - 0.05f) && (openHi || g0[a] <= hi + 0.05f);
-                    ta = inside ? -3.0e38f : 3.0e38f; tb = inside ? 3.0e38f : -3.0e38f;
-                }
-                tin = fmaxf(tin, fminf(ta, tb));
-                tout = fminf(tout, fmaxf(ta, tb));
-            }
-            march = tin <= tout;
-        }
-        if (march) {
-            const float *data = m.grids + sdf.dataOff;
-            // header fields in registers for the march (the compiler does not hoist loads through the SdfDev reference)
-            const float res = sdf.res, rcp = sdf.rcpRes, ox = sdf.ox, oy = sdf.oy, oz = sdf.oz;
-            const bool exactDiv = sdf.divExact != 0;
-            const int dimx = sdf.dimx, dimy = sdf.dimy, nbx = sdf.nbx, nby = sdf.nby;
-            auto eval = [&](float tt) -> float {
-                f3 xf, xg;
-                xf.x = dn.x * tt + of.x; xf.y = dn.y * tt + of.y; xf.z = dn.z * tt + of.z;
-                const float dx = xf.x - ox, dy = xf.y - oy, dz = xf.z - oz;
-                if (exactDiv) { xg.x = div_exact(dx, res, rcp); xg.y = div_exact(dy, res, rcp); xg.z = div_exact(dz, res, rcp); }
-                else { xg.x = dx / res; xg.y = dy / res; xg.z = dz / res; }
-                xg.x = fmaxf(1.0f, fminf(xg.x, hix));
-                xg.y = fmaxf(1.0f, fminf(xg.y, hiy));
-                xg.z = fmaxf(1.0f, fminf(xg.z, hiz));
-                return sdf_lookup<CNT_RAYCAST>(data, dimx, dimy, nbx, nby, xg) * res;
-            };
-            float sdfValPrev = eval(t0);
-            float tPrev = t0;
-#ifdef DARTK_STAMPS
-            int steps = 0;
-#endif
-            const float minStep = res / 10;
-            while (t0 < t1 && t0 < 10000.0f) {      // 10000 = the reference's initial closestT
-                const float sdfVal = eval(t0);
-                if (sdfValPrev > levelSet && sdfVal <= levelSet) {
-                    det = t0;
-                    hit = (t0 - tPrev) * (levelSet - sdfValPrev) / (sdfVal - sdfValPrev) + tPrev;
-                    break;      // the reference's loop ends here too: closestT = hit <= t0 < the next t0
-                }
-                sdfValPrev = sdfVal;
-                tPrev = t0;
-                t0 += fmaxf(minStep, fabsf(sdfVal));
-#ifdef DARTK_STAMPS
-                ++steps;
-#endif
-            }
-#ifdef DARTK_STAMPS
-            atomicMax(&g_rayMaxSteps, steps);
-            atomicAdd(&g_raySteps, (unsigned long long)steps);
-            atomicAdd(&g_rayMarched, 1ull);
-#endif
-        }
+        bool want; float det, hit;
+        trace_one_ray<true>(m, s, x, y, flx, fly, ppx, ppy, slot, levelSet, want, det, hit);
         count_lookup<CNT_OTHER>();                  // (diagnostic build: trace records written)
         trace[(size_t)task * 64 + lane] = make_float2(det, hit);
     }
