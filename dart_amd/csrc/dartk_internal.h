@@ -117,6 +117,15 @@ void set_error(const char *fmt, ...);
         if (!(cond)) { dartk::set_error(__VA_ARGS__); return DARTK_ERR_INVALID; }            \
     } while (0)
 
+// one deferred slab reduction (see Workspace::deferReduce)
+struct ReduceJob {
+    const float *slabs;
+    float *result;
+    const int *count;       // gate: keep the sum only if *count > minCount (null: `keep`)
+    int nBlocks, S, keep, minCount;
+};
+static constexpr int kMaxReduceJobs = 48;
+
 // per-device workspace: partial-system slabs for the deterministic two-pass reductions
 struct Workspace {
     float *partials;       // [maxBlocks][maxSys]
@@ -131,10 +140,22 @@ struct Workspace {
     int partialLane;       // which third of `partials` the next term wrapper uses (device loops run three chains side by side)
     hipStream_t auxStream2; // third stream: the per-call obs-SDF build runs beside the first ray-cast
     hipEvent_t evFork, evJoin, evObs, evJoin2, evTrace;
+    // The multi-model loop's term wrappers each end in a slab reduction of their own (seven small launches per iteration, and
+    // that loop is bound by the host's launches). deferReduce: the wrappers only note their reduction (reduceJobs) and leave
+    // their slabs at deferOffset[lane] of their lane; ONE launch after the chains have joined reduces all of them
+    // (flush_reduce_jobs). measureLanes: a dry pass that adds up what a lane would need (laneNeed), so that the slab buffer can
+    // be grown BEFORE slabs that must survive until the flush are in it.
+    bool deferReduce, measureLanes;
+    int nReduceJobs;
+    size_t deferOffset[3], laneNeed[3];
+    ReduceJob reduceJobs[kMaxReduceJobs];
 };
 static constexpr int kPartialLanes = 3;
 // the slab buffer of the current lane; partialFloats is the capacity of ONE lane
-inline float *lane_partials(Workspace *w) { return w->partials + (size_t)w->partialLane * w->partialFloats; }
+inline float *lane_partials(Workspace *w) {
+    return w->partials + (size_t)w->partialLane * w->partialFloats + (w->deferReduce ? w->deferOffset[w->partialLane] : 0);
+}
+int flush_reduce_jobs(Workspace *w, hipStream_t st);
 int get_workspace(Workspace **ws);
 static constexpr int kMaxPartialBlocks = 2048;
 static constexpr int kMaxDims = 70;                       // 6 + DARTK_MAX_JOINTS

@@ -106,6 +106,13 @@ int get_multi_args_buffer(void **d_ptr, size_t bytes) {
 }
 
 int ensure_partials(Workspace *w, size_t floats) {
+    const size_t aligned = (floats + 63) / 64 * 64;
+    if (w->measureLanes) w->laneNeed[w->partialLane] += aligned;
+    if (w->deferReduce) {       // the lane already holds slabs that wait for the flush: it cannot be re-allocated now
+        DARTK_REQUIRE(w->deferOffset[w->partialLane] + floats <= w->partialFloats, "deferred reductions: slab lane %d overflows (%zu + %zu > %zu floats)",
+                      w->partialLane, w->deferOffset[w->partialLane], floats, w->partialFloats);
+        return DARTK_OK;
+    }
     if (floats <= w->partialFloats) return DARTK_OK;
     DARTK_HIP(hipDeviceSynchronize());
     DARTK_HIP(hipFree(w->partials));
@@ -170,7 +177,68 @@ reduce_slabs_kernel(const float *__restrict__ slabs, int nBlocks, int S, float *
     }
 }
 
+// every noted reduction in one launch: grid (outputs / 32, frame, job)
+struct ReduceJobTable { int n; ReduceJob job[kMaxReduceJobs]; };
+__global__ void __launch_bounds__(kReduceOuts * kReduceSegs)
+reduce_slabs_jobs_kernel(ReduceJobTable t, FrameBatch fb) {
+    __shared__ double part[kReduceSegs][kReduceOuts + 1];
+    const ReduceJob &j = t.job[blockIdx.z];
+    const int S = j.S, nBlocks = j.nBlocks;
+    if ((int)(blockIdx.x * kReduceOuts) >= S) return;
+    const float *__restrict__ slabs = j.slabs + (size_t)blockIdx.y * nBlocks * S;
+    float *__restrict__ result = j.result + (size_t)blockIdx.y * fb.sys;
+    const int col = threadIdx.x % kReduceOuts, seg = threadIdx.x / kReduceOuts;
+    const int o = blockIdx.x * kReduceOuts + col;
+    const int keep = j.count ? (j.count[(size_t)blockIdx.y * fb.counts] > j.minCount) : j.keep;
+    double s = 0.0;
+    if (keep && o < S) {        // the sums of reduce_slabs_kernel, term for term
+        int b = seg;
+        for (; b + 3 * kReduceSegs < nBlocks; b += 4 * kReduceSegs) {
+            const float v0 = slabs[(size_t)b * S + o];
+            const float v1 = slabs[(size_t)(b + kReduceSegs) * S + o];
+            const float v2 = slabs[(size_t)(b + 2 * kReduceSegs) * S + o];
+            const float v3 = slabs[(size_t)(b + 3 * kReduceSegs) * S + o];
+            s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+        }
+        for (; b < nBlocks; b += kReduceSegs) s += (double)slabs[(size_t)b * S + o];
+    }
+    part[seg][col] = s;
+    __syncthreads();
+    if (seg == 0 && o < S) {
+        double tt = 0.0;
+        for (int g = 0; g < kReduceSegs; ++g) tt += part[g][col];
+        result[o] = (float)tt;
+    }
+}
+
+static bool defer_reduce(const float *slabs, int nBlocks, int S, float *result, int keep, const int *count, int minCount, int *rc) {
+    Workspace *w;
+    if (get_workspace(&w) != DARTK_OK || !w->deferReduce) return false;
+    *rc = DARTK_OK;
+    if (w->nReduceJobs >= kMaxReduceJobs) { set_error("more than %d deferred reductions in one iteration", kMaxReduceJobs); *rc = DARTK_ERR_INVALID; return true; }
+    w->reduceJobs[w->nReduceJobs++] = ReduceJob{slabs, result, count, nBlocks, S, keep, minCount};
+    w->deferOffset[w->partialLane] += ((size_t)cur_batch().n * nBlocks * S + 63) / 64 * 64;
+    return true;
+}
+
+int flush_reduce_jobs(Workspace *w, hipStream_t st) {
+    if (w->nReduceJobs > 0) {
+        ReduceJobTable t;
+        t.n = w->nReduceJobs;
+        int maxS = 1;
+        for (int i = 0; i < t.n; ++i) { t.job[i] = w->reduceJobs[i]; if (t.job[i].S > maxS) maxS = t.job[i].S; }
+        hipLaunchKernelGGL(reduce_slabs_jobs_kernel, dim3((maxS + kReduceOuts - 1) / kReduceOuts, cur_batch().n, t.n), dim3(kReduceOuts * kReduceSegs),
+                           0, st, t, cur_batch());
+        DARTK_HIP(hipGetLastError());
+    }
+    w->nReduceJobs = 0;
+    for (int l = 0; l < kPartialLanes; ++l) w->deferOffset[l] = 0;
+    return DARTK_OK;
+}
+
 int launch_reduce_slabs(const float *slabs, int nBlocks, int S, float *result, int keep, hipStream_t stream) {
+    int drc;
+    if (defer_reduce(slabs, nBlocks, S, result, keep, nullptr, 0, &drc)) return drc;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((S + kReduceOuts - 1) / kReduceOuts, cur_batch().n), dim3(kReduceOuts * kReduceSegs), 0,
                        stream, slabs, nBlocks, S, result, keep, (const int *)nullptr, 0, cur_batch());
     DARTK_HIP(hipGetLastError());
@@ -179,6 +247,8 @@ int launch_reduce_slabs(const float *slabs, int nBlocks, int S, float *result, i
 
 int launch_reduce_slabs_gated(const float *slabs, int nBlocks, int S, float *result, const int *d_count, int minCount,
                               hipStream_t stream) {
+    int drc;
+    if (defer_reduce(slabs, nBlocks, S, result, 0, d_count, minCount, &drc)) return drc;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((S + kReduceOuts - 1) / kReduceOuts, cur_batch().n), dim3(kReduceOuts * kReduceSegs), 0,
                        stream, slabs, nBlocks, S, result, 0, d_count, minCount, cur_batch());
     DARTK_HIP(hipGetLastError());

@@ -545,7 +545,17 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     // Three chains per iteration meet only in the solve: ray-cast -> cull -> mod->obs (the longest, on the caller's stream),
     // association -> obs->mod, and the intersection terms; the two shorter ones run on the side streams, each term wrapper
     // writing its partial systems into its chain's lane of the slab buffer.
-    struct LaneGuard { Workspace *w; ~LaneGuard() { w->partialLane = 0; } } laneGuard{ws};
+    struct LaneGuard {
+        Workspace *w;
+        ~LaneGuard() {
+            w->partialLane = 0; w->deferReduce = false; w->measureLanes = false; w->nReduceJobs = 0;
+            for (int l = 0; l < kPartialLanes; ++l) w->deferOffset[l] = 0;
+        }
+    } laneGuard{ws};
+    // From the second iteration on the terms' slab reductions are noted and done by ONE launch after the chains have joined
+    // (Workspace::deferReduce): seven launches less per iteration in a loop whose pace is the host's launches. The first iteration
+    // runs as before and adds up what each chain's slabs need, so that the buffer is grown before anything has to survive in it.
+    const bool deferLater = o->numIterations > 1 && getenv("DARTK_NO_DEFER_REDUCE") == nullptr && 2 * n + n + n * n <= kMaxReduceJobs;
     if (useB) { rc = gn_raycast_reserve(traceFloats * nFrames); if (rc) return rc; }
     const bool par = o->numIterations > 0 && getenv("DARTK_MULTI_ONE_STREAM") == nullptr;
     hipStream_t stA = par ? ws->auxStream : st, stC = par ? ws->auxStream2 : st;
@@ -567,6 +577,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
             joinGuard.on = true;
         }
         ws->partialLane = 0;
+        if (deferLater && it == 0) { ws->measureLanes = true; for (int l = 0; l < kPartialLanes; ++l) ws->laneNeed[l] = 0; }
         if (useB) {     // raytracePrediction of every model into one map + cullUnobservable (:610-618)
             // the traces of the models are independent: the first runs here, the others on the intersection chain's stream
             // ahead of its terms; the replays follow in model order on this stream (they share the prediction map)
@@ -636,12 +647,22 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
             DARTK_HIP(hipStreamWaitEvent(st, ws->evJoin2, 0));
             joinGuard.on = false;
         }
+        if (ws->deferReduce) { rc = flush_reduce_jobs(ws, st); if (rc) return rc; }
         {
             ProfScope ps(DARTK_PROF_SOLVE, st);
             hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64), ldsSolve, st, d_args, it);
         }
         DARTK_HIP(hipGetLastError());
+        if (deferLater && it == 0) {
+            ws->measureLanes = false;
+            size_t need = 0;
+            for (int l = 0; l < kPartialLanes; ++l) need = ws->laneNeed[l] > need ? ws->laneNeed[l] : need;
+            rc = ensure_partials(ws, need);         // (waits for the device if it has to grow the buffer: first call only)
+            if (rc) return rc;
+            ws->deferReduce = true;
+        }
     }
+    ws->deferReduce = false;
     if (batch) {                // export the poses
         hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64), ldsSolve, st, d_args, -2);
         DARTK_HIP(hipGetLastError());
