@@ -83,7 +83,7 @@ int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr
                            dartk_da_point *const *pts, void **d_args_out, hipStream_t st, size_t *stageBytes = nullptr);
 // stageBytes (from the prepare call): LDS for the staged form of the kernel, 0 = read the tables from memory
 int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void *d_args, int *d_last, hipStream_t st,
-                          const int *d_validIdx = nullptr, const int *d_nValid = nullptr, size_t stageBytes = 0);
+                          const int *d_validIdx = nullptr, const int *d_nValid = nullptr, size_t stageBytes = 0, bool zeroCounts = true);
 int gn_ne_mod2obs_any(int red, int fullDims, int redDims, const float *d_pred, int width, int height, Model *mod,
                       const float *d_T_gc, const float *d_A, const int *d_map, float *d_result, int *d_num, hipStream_t st,
                       const int *d_nItems = nullptr);

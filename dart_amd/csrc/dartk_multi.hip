@@ -46,6 +46,9 @@ struct MultiSolveArgs {
     // contact priors of the single-frame loop (optimizer.cpp:727-732, 757-759): device array, contact points updated in place
     dartk_contact_prior *priors;
     int nPriors;
+    // the association / prediction counters of a frame (fb.counts ints each): cleared here for the next iteration's kernels
+    // instead of by two memset launches per iteration (null: the term is off)
+    int *zeroA, *zeroB;
 };
 
 // projection of the reduced articulation in ra[] (LDS) to the full joint vector (pose.cpp:66-73, 91-97) and forward
@@ -320,6 +323,11 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration) {
         project_and_fk(m, v, ra, sT);
         wave_sync_lds();
     }
+    // this iteration's counts have been read (summaries above, the gated reductions before this launch): ready for the next
+    if (lane < DARTK_MAX_MODELS) {       // (the arrays hold DARTK_MAX_MODELS counters per frame in either form of the loop)
+        if (a.zeroA) a.zeroA[co + lane] = 0;
+        if (a.zeroB) a.zeroB[co + lane] = 0;
+    }
 }
 
 // per-device buffers of the loop (argument block, per-term systems, small tables)
@@ -482,6 +490,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     h.lambdaA = o->lambdaObsToMod; h.lambdaB = o->lambdaModToObs;
     h.iterInfo = d_iterInfo; h.firstSystem = d_firstSystem;
     h.priors = d_priors; h.nPriors = nPriors;
+    h.zeroA = useA ? d_countA : nullptr; h.zeroB = useB ? d_countB : nullptr;
     h.fb = fb; h.redStride = batch ? redTotal : 0; h.infoStride = batch ? (size_t)o->numIterations * n * 8 : 0; h.T_mcs = d_T_mcs;
     {   // argument block and tables leave through a pinned slot: the call does not wait for the stream
         ArgSlot slot;
@@ -569,6 +578,8 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
             (void)hipStreamWaitEvent(st, w->evJoin, 0); (void)hipStreamWaitEvent(st, w->evJoin2, 0);
         }
     } joinGuard{ws, st, stA, stC, false};
+    // both counter arrays start at zero; every solve launch leaves them cleared for the next iteration
+    DARTK_HIP(hipMemsetAsync(d_countA, 0, 2 * (size_t)DARTK_MAX_MODELS * nFrames * sizeof(int), st));
     for (int it = 0; it < o->numIterations; ++it) {
         if (par) {      // the poses of this iteration are final on `st`
             DARTK_HIP(hipEventRecord(ws->evFork, st));
@@ -594,7 +605,6 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
             // a batch keeps no prediction maps for the caller: the replay leaves each frame's hits as a list (a few percent of the
             // map) and the mod->obs terms walk the list; the hit counter of a frame sits in the last slot of its prediction counters
             int *d_hits = (batch && n < DARTK_MAX_MODELS && gn_replay_hit_lists(n, mods)) ? d_countB + (DARTK_MAX_MODELS - 1) : nullptr;
-            DARTK_HIP(hipMemsetAsync(d_countB, 0, (batch ? (size_t)DARTK_MAX_MODELS * nFrames : (size_t)n) * sizeof(int), st));
             rc = gn_launch_raycast_replay_cull_multi(o->predFl[0], o->predFl[1], ppx, ppy, o->predWidth, o->predHeight, n, mods, traceOff,
                                                      d_prediction, d_vert, width, height, st, d_hits);
             if (rc) return rc;
@@ -610,7 +620,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         if (useA) {
             {
                 ProfScope ps(DARTK_PROF_OTHER, stA);
-                rc = gn_assoc_multi_launch(d_vert, nPix, n, d_assocArgs, d_countA, stA, d_validIdx, d_nValid, assocStageBytes);
+                rc = gn_assoc_multi_launch(d_vert, nPix, n, d_assocArgs, d_countA, stA, d_validIdx, d_nValid, assocStageBytes, false);
                 if (rc) return rc;
             }
             for (int m = 0; m < n; ++m) {

@@ -436,9 +436,9 @@ int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr
     return DARTK_OK;
 }
 int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void *d_args, int *d_last, hipStream_t st,
-                          const int *d_validIdx, const int *d_nValid, size_t stageBytes) {
+                          const int *d_validIdx, const int *d_nValid, size_t stageBytes, bool zeroCounts) {
     const FrameBatch fb = cur_batch();
-    DARTK_HIP(hipMemsetAsync(d_last, 0, (fb.n > 1 ? (size_t)fb.n * fb.counts : (size_t)nModels) * sizeof(int), st));
+    if (zeroCounts) DARTK_HIP(hipMemsetAsync(d_last, 0, (fb.n > 1 ? (size_t)fb.n * fb.counts : (size_t)nModels) * sizeof(int), st));
     int wgs = (nPix + 255) / 256;
     if (d_validIdx) { const int cap = fb.n > 1 ? (8192 / fb.n > 16 ? 8192 / fb.n : 16) : 2048; if (wgs > cap) wgs = cap; }
     // with a valid-pixel list the grid is chip-sized and each workgroup walks many pixels: the tables are worth staging
