@@ -37,7 +37,7 @@ int arg_ring_release(const ArgSlot &s, hipStream_t st);
 int ensure_partials(Workspace *w, size_t floats);
 void registry_add(Model *m);           // dartk_tables.hip: live model handles by their device arrays
 void registry_remove(Model *m);
-int noalloc_scratch(float **out);      // dartk_obs2mod.hip: device address of the no-allocation entry point's scratch array
+int noalloc_scratch_resolve();         // dartk_obs2mod.hip: resolves the current device's address of the no-allocation entry point's scratch array (dartk_init)
 int get_multi_args_buffer(void **d_ptr, size_t bytes);
 int ensure_ray_buf(Workspace *w, size_t floats);
 // floats of ray-cast trace records one model can need: {detection t, hit t} per pixel of every 8x8 tile, per SDF
@@ -79,6 +79,9 @@ int gn_launch_ne_self(const float *d_sites, int nSites, const ModelView &m, cons
 int gn_launch_ne_obs2mod_dev(int red, int fullDims, int redDims, const float *d_vert, Model *mod, float huberDelta,
                              const dartk_da_point *d_pts, const int *d_count, int maxElements, const float *d_A,
                              const int *d_map, float *d_result, hipStream_t st);
+int gn_assoc_multi_entry(const float *d_vert, const float *d_norm, int width, int height, int nModels, const dartk_model_t *models,
+                         const float *d_T_mcs, const float *h_distThresholds, const float *h_planeOffsets, const float *h_planeNormals3,
+                         dartk_da_point *const *h_pts_table, int32_t *d_last, int32_t *d_dbgDA, float *d_dbgErr, void *stream);
 int gn_assoc_multi_prepare(int nModels, Model *const *mods, const float *distThr, const float *planeOffset, const float *pn3,
                            dartk_da_point *const *pts, void **d_args_out, hipStream_t st, size_t *stageBytes = nullptr);
 // stageBytes (from the prepare call): LDS for the staged form of the kernel, 0 = read the tables from memory

@@ -245,6 +245,14 @@ int launch_reduce_slabs(const float *slabs, int nBlocks, int S, float *result, i
     return DARTK_OK;
 }
 
+// one frame, now, on `stream`: no workspace, no deferred-job table, no batch scope (dartk_ne_obs2mod_noalloc)
+int launch_reduce_slabs_direct(const float *slabs, int nBlocks, int S, float *result, hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((S + kReduceOuts - 1) / kReduceOuts, 1), dim3(kReduceOuts * kReduceSegs), 0, stream,
+                       slabs, nBlocks, S, result, 1, (const int *)nullptr, 0, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0});
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
 int launch_reduce_slabs_gated(const float *slabs, int nBlocks, int S, float *result, const int *d_count, int minCount,
                               hipStream_t stream) {
     int drc;
@@ -293,7 +301,7 @@ int dartk_init(int device) {
     Workspace *w;
     int rc = get_workspace(&w);
     if (rc) return rc;
-    return noalloc_scratch(nullptr);        // resolve this device's address of the no-allocation scratch array once
+    return noalloc_scratch_resolve();       // resolve this device's address of the no-allocation scratch array once
 }
 
 int dartk_buf_alloc(void **d_ptr, size_t bytes) {

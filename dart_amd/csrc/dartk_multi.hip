@@ -755,8 +755,10 @@ int dartk_optimize_poses_batch(const dartk_multi_options *o, const dartk_multi_m
                       o->predWidth, o->predHeight, width, height);
     }
     // frames in chunks that bound the per-call device memory (association lists, traces, prediction maps: ~50 MB per 1280x720 frame)
-    static const char *env = getenv("DARTK_BATCH_CHUNK");
-    const int chunk = env ? atoi(env) : 64;
+    // (DARTK_BATCH_CHUNK is read on every call so that a test can move the chunk seam; anything but a positive number = 64)
+    const char *env = getenv("DARTK_BATCH_CHUNK");
+    int chunk = env ? atoi(env) : 64;
+    if (chunk < 1) chunk = 64;
     hipStream_t st = as_stream(stream);
     const size_t mapFloats = 4 * (size_t)width * height;
     for (int f0 = 0; f0 < nFrames; f0 += chunk) {

@@ -349,8 +349,8 @@ int gn_launch_ne_obs2mod_dev(int red, int fullDims, int redDims, const float *d_
 // dartk_ne_obs2mod_noalloc. The partial-system slabs -- the one scratch buffer of this term, which dartk_ne_obs2mod takes
 // from the library's hipMalloc'ed workspace -- live in a file-scope device array of a fixed, modest size (kNoAllocMaxBlocks
 // slabs of a system of up to kNoAllocMaxDims dimensions = 561 KiB per GPU, held until the process ends). `scratch` itself is a
-// host-side stand-in for the symbol: the device address is looked up once per device (hipGetSymbolAddress, at dartk_init or
-// at the entry point's first call on that device) and only that pointer is ever handed to kernels. Nothing has to be
+// host-side stand-in for the symbol: the device address is looked up once per device (hipGetSymbolAddress, in dartk_init; the
+// entry point refuses a device dartk_init has not seen) and only that pointer is ever handed to kernels. Nothing has to be
 // cleared between calls: every launched workgroup overwrites its whole slab and the reduction reads exactly the slabs of
 // this launch. Calls that overlap on one GPU share the array and race.
 // -----------------------------------------------------------------------------------------------------
@@ -360,8 +360,8 @@ static constexpr size_t kNoAllocFloats = (size_t)kNoAllocMaxBlocks * sys_size(kN
 static __device__ __align__(256) float scratch[kNoAllocFloats];
 static float *g_scratchPtr[16] = {nullptr};       // per device: each GPU holds its own copy of the array at its own address
 
-// device address of this device's `scratch` (the device must be current); no allocation
-int noalloc_scratch(float **out) {
+// dartk_init(device): resolves this device's address of `scratch` (the device must be current); no allocation
+int noalloc_scratch_resolve() {
     int dev = 0;
     DARTK_HIP(hipGetDevice(&dev));
     DARTK_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
@@ -371,7 +371,17 @@ int noalloc_scratch(float **out) {
         DARTK_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned a null address for the no-allocation scratch array");
         g_scratchPtr[dev] = ptr;
     }
-    if (out) *out = g_scratchPtr[dev];
+    return DARTK_OK;
+}
+
+// the entry point's side: the address dartk_init resolved for the current device, or an error -- nothing is initialised lazily
+// inside the call (dartk_init creates the library's workspace, streams and events, which allocates)
+static int noalloc_scratch(float **out) {
+    int dev = 0;
+    DARTK_HIP(hipGetDevice(&dev));
+    DARTK_REQUIRE(dev >= 0 && dev < 16 && g_scratchPtr[dev],
+                  "dartk_ne_obs2mod_noalloc: dartk_init(%d) has not run on this device (the scratch address is resolved there, not inside the call)", dev);
+    *out = g_scratchPtr[dev];
     return DARTK_OK;
 }
 
@@ -395,14 +405,19 @@ static int launch_ne_obs2mod_noalloc(int dims, const float *d_vert, Model *mod, 
     const size_t ldsBytes = ne_obs2mod_lds_bytes(m, dims, 0);
     DARTK_REQUIRE(ldsBytes <= 64 * 1024, "LDS requirement %zu exceeds the 64 KiB a launch gets without an attribute call", ldsBytes);
     const float4 *vert = reinterpret_cast<const float4 *>(d_vert);
-    if (S <= 3 * NE_BLOCK)
-        hipLaunchKernelGGL((ne_obs2mod_kernel<3, 0>), dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, nElements, m, huberDelta,
-                           dims, (const float *)nullptr, (const int *)nullptr, slabs, (const int *)nullptr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0});
-    else
-        hipLaunchKernelGGL((ne_obs2mod_kernel<6, 0>), dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, nElements, m, huberDelta,
-                           dims, (const float *)nullptr, (const int *)nullptr, slabs, (const int *)nullptr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0});
+    const FrameBatch one{1, 0, 0, 0, 0, 0, 0, 0};
+    // the instantiation dartk_ne_obs2mod picks for this system size (launch_ne_obs2mod)
+#define DARTK_LAUNCH_NA(PPT_)                                                                                             \
+    hipLaunchKernelGGL((ne_obs2mod_kernel<PPT_, 0>), dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, d_pts, vert, nElements, m, huberDelta, \
+                       dims, (const float *)nullptr, (const int *)nullptr, slabs, (const int *)nullptr, one)
+    if (S <= NE_BLOCK) DARTK_LAUNCH_NA(1);
+    else if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_NA(3);
+    else DARTK_LAUNCH_NA(6);
+#undef DARTK_LAUNCH_NA
     DARTK_HIP(hipGetLastError());
-    return launch_reduce_slabs(slabs, nBlocks, S, d_result, 1, st);
+    // straight to the reduction kernel: launch_reduce_slabs would consult the workspace (which get_workspace creates on first
+    // use) and a deferred-reduction table that belongs to another call
+    return launch_reduce_slabs_direct(slabs, nBlocks, S, d_result, st);
 }
 
 // multi-model association for the device-resident loop: the argument block is uploaded once per optimizePoses call
@@ -452,6 +467,51 @@ int gn_assoc_multi_launch(const float *d_vert, int nPix, int nModels, const void
     return DARTK_OK;
 }
 
+// dartk_assoc_multi; d_T_mcs (device, [nModels][12], may be null) replaces the models' own camera -> model transforms for this
+// launch only, as the reference's kernel argument does (obsToMod.h:88-107): the models are not touched
+int gn_assoc_multi_entry(const float *d_vert, const float *d_norm, int width, int height, int nModels, const dartk_model_t *models,
+                         const float *d_T_mcs, const float *h_distThresholds, const float *h_planeOffsets, const float *h_planeNormals3,
+                         dartk_da_point *const *h_pts_table, int32_t *d_last, int32_t *d_dbgDA, float *d_dbgErr, void *stream) {
+    (void)d_norm;
+    DARTK_REQUIRE(d_vert && models && h_distThresholds && h_planeOffsets && h_planeNormals3 && h_pts_table && d_last,
+                  "dartk_assoc_multi: null argument");
+    DARTK_REQUIRE(nModels >= 1 && nModels <= DARTK_MAX_MODELS, "nModels %d out of range [1,%d]", nModels, DARTK_MAX_MODELS);
+    DARTK_REQUIRE(width > 0 && height > 0 && (long long)width * height < (1ll << 31), "bad map size %dx%d", width, height);
+    hipStream_t st = as_stream(stream);
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    // the argument block goes through the ring of pinned slots: no host wait per call (the reference's wrapper does not block either)
+    ArgSlot slot;
+    rc = arg_ring_acquire(sizeof(MultiArgs), &slot);
+    if (rc) return rc;
+    MultiArgs &hargs = *reinterpret_cast<MultiArgs *>(slot.h);
+    hargs.nModels = nModels;
+    for (int i = 0; i < nModels; ++i) {
+        Model *mod = reinterpret_cast<Model *>(models[i]);
+        DARTK_REQUIRE(mod && h_pts_table[i], "dartk_assoc_multi: null model or point buffer %d", i);
+        hargs.m[i] = mod->v;
+        if (d_T_mcs) hargs.m[i].T_mc = const_cast<float *>(d_T_mcs) + 12 * i;
+        hargs.distThr[i] = h_distThresholds[i];
+        hargs.planeOffset[i] = h_planeOffsets[i];
+        for (int k = 0; k < 3; ++k) hargs.pn[i][k] = h_planeNormals3[3 * i + k];
+        hargs.pts[i] = h_pts_table[i];
+    }
+    MultiArgs *d_args = reinterpret_cast<MultiArgs *>(slot.d);
+    DARTK_HIP(hipMemcpyAsync(d_args, &hargs, sizeof(MultiArgs), hipMemcpyHostToDevice, st));
+    DARTK_HIP(hipMemsetAsync(d_last, 0, nModels * sizeof(int), st));
+    const int nPix = width * height;
+    const dim3 grid((nPix + 255) / 256), block(256);
+    if (d_dbgDA || d_dbgErr)
+        hipLaunchKernelGGL(assoc_multi_kernel<true>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, d_dbgDA, d_dbgErr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0},
+                           (const int *)nullptr, (const int *)nullptr);
+    else
+        hipLaunchKernelGGL(assoc_multi_kernel<false>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, nullptr, nullptr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0},
+                           (const int *)nullptr, (const int *)nullptr);
+    DARTK_HIP(hipGetLastError());
+    return arg_ring_release(slot, st);
+}
+
 DARTK_COUNTER_ACCESS(obs2mod)
 
 }  // namespace dartk
@@ -492,43 +552,8 @@ int dartk_assoc_multi(const float *d_vert, const float *d_norm, int width, int h
                       const dartk_model_t *models, const float *h_distThresholds, const float *h_planeOffsets,
                       const float *h_planeNormals3, dartk_da_point *const *h_pts_table, int32_t *d_last,
                       int32_t *d_dbgDA, float *d_dbgErr, void *stream) {
-    (void)d_norm;
-    DARTK_REQUIRE(d_vert && models && h_distThresholds && h_planeOffsets && h_planeNormals3 && h_pts_table && d_last,
-                  "dartk_assoc_multi: null argument");
-    DARTK_REQUIRE(nModels >= 1 && nModels <= DARTK_MAX_MODELS, "nModels %d out of range [1,%d]", nModels, DARTK_MAX_MODELS);
-    DARTK_REQUIRE(width > 0 && height > 0 && (long long)width * height < (1ll << 31), "bad map size %dx%d", width, height);
-    hipStream_t st = as_stream(stream);
-    Workspace *ws;
-    int rc = get_workspace(&ws);
-    if (rc) return rc;
-    // the argument block goes through the ring of pinned slots: no host wait per call (the reference's wrapper does not block either)
-    ArgSlot slot;
-    rc = arg_ring_acquire(sizeof(MultiArgs), &slot);
-    if (rc) return rc;
-    MultiArgs &hargs = *reinterpret_cast<MultiArgs *>(slot.h);
-    hargs.nModels = nModels;
-    for (int i = 0; i < nModels; ++i) {
-        Model *mod = reinterpret_cast<Model *>(models[i]);
-        DARTK_REQUIRE(mod && h_pts_table[i], "dartk_assoc_multi: null model or point buffer %d", i);
-        hargs.m[i] = mod->v;
-        hargs.distThr[i] = h_distThresholds[i];
-        hargs.planeOffset[i] = h_planeOffsets[i];
-        for (int k = 0; k < 3; ++k) hargs.pn[i][k] = h_planeNormals3[3 * i + k];
-        hargs.pts[i] = h_pts_table[i];
-    }
-    MultiArgs *d_args = reinterpret_cast<MultiArgs *>(slot.d);
-    DARTK_HIP(hipMemcpyAsync(d_args, &hargs, sizeof(MultiArgs), hipMemcpyHostToDevice, st));
-    DARTK_HIP(hipMemsetAsync(d_last, 0, nModels * sizeof(int), st));
-    const int nPix = width * height;
-    const dim3 grid((nPix + 255) / 256), block(256);
-    if (d_dbgDA || d_dbgErr)
-        hipLaunchKernelGGL(assoc_multi_kernel<true>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, d_dbgDA, d_dbgErr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0},
-                           (const int *)nullptr, (const int *)nullptr);
-    else
-        hipLaunchKernelGGL(assoc_multi_kernel<false>, grid, block, 0, st, (const float4 *)d_vert, nPix, d_args, d_last, nullptr, nullptr, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0},
-                           (const int *)nullptr, (const int *)nullptr);
-    DARTK_HIP(hipGetLastError());
-    return arg_ring_release(slot, st);
+    return gn_assoc_multi_entry(d_vert, d_norm, width, height, nModels, models, nullptr, h_distThresholds, h_planeOffsets, h_planeNormals3,
+                                h_pts_table, d_last, d_dbgDA, d_dbgErr, stream);
 }
 
 int dartk_ne_obs2mod(int dims, const float *d_vert, int width, int height, dartk_model_t h, float huberDelta,

@@ -250,6 +250,7 @@ __device__ __forceinline__ int compact_slot(bool active, int *waveCnt, int &tota
 // "nElements > 10" gate leaves the memset system untouched); the gated form reads that decision on the device
 // (*d_count > minCount).
 int launch_reduce_slabs(const float *slabs, int nBlocks, int S, float *result, int keep, hipStream_t stream);
+int launch_reduce_slabs_direct(const float *slabs, int nBlocks, int S, float *result, hipStream_t stream);
 int launch_reduce_slabs_gated(const float *slabs, int nBlocks, int S, float *result, const int *d_count, int minCount,
                               hipStream_t stream);
 

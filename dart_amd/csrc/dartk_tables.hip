@@ -74,10 +74,10 @@ int dartk_assoc_multi_tables(const float *d_vert, const float *d_norm, int width
         Model *mod = registry_find(tab[m]);
         DARTK_REQUIRE(mod, "dartk_assoc_multi_tables: T_fms[%d] is not a device array of a live dartk model", m);
         handles[m] = reinterpret_cast<dartk_model_t>(mod);
-        if (d_T_mcs)        // the argument is authoritative, as in the reference (optimizer.cpp:603-608 uploads the models' T_mc)
-            DARTK_HIP(hipMemcpyAsync(mod->v.T_mc, d_T_mcs + 12 * m, 12 * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
-    return dartk_assoc_multi(d_vert, d_norm, width, height, nModels, handles, thr, po, pn, pts, d_lastElements, d_dbgDA, d_dbgErr, stream);
+    // T_mcs is authoritative for this launch, as in the reference (optimizer.cpp:603-608 uploads the models' T_mc as a kernel
+    // argument), and only for it: the models' own T_mc / T_cm stay as they are
+    return gn_assoc_multi_entry(d_vert, d_norm, width, height, nModels, handles, d_T_mcs, thr, po, pn, pts, d_lastElements, d_dbgDA, d_dbgErr, stream);
 }
 
 int dartk_raycast_prediction_tables(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum,

@@ -94,10 +94,12 @@ class Optimizer:
         self.iter_info, self.first_system = info, first
 
 
-def depth_to_vertices(depth, pp, fl, depth_range=(0.1, 5.0)):
-    """PointCloudSource::projectDepthMap -> depthToVertices (point_cloud_src.h:261-285)."""
+def depth_to_vertices(depth, pp, fl, depth_range=(0.1, 5.0), out=None):
+    """PointCloudSource::projectDepthMap -> depthToVertices (point_cloud_src.h:261-285). `out`: an existing [h, w, 4] vertex
+    map to update; pixels whose depth is out of range only get w = 0 and keep their x, y, z (organized_point_cloud.cu:36-38)."""
     h, w = depth.shape
-    vert = torch.zeros((h, w, 4), dtype=torch.float32, device=depth.device)
+    vert = torch.zeros((h, w, 4), dtype=torch.float32, device=depth.device) if out is None else out
+    assert vert.shape == (h, w, 4) and vert.dtype == torch.float32 and vert.is_contiguous()
     check(lib().dartk_depth_to_vertices(device._ptr(depth), device._ptr(vert), w, h, pp[0], pp[1], fl[0], fl[1],
                                         depth_range[0], depth_range[1], device._stream()))
     return vert

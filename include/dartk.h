@@ -123,8 +123,9 @@ int dartk_assoc_multi(const float *d_vert, const float *d_norm, int width, int h
                       int32_t *d_dbgDA, float *d_dbgErr, void *stream);
 /* errorAndDataAssociationMultiModel with the reference's OWN argument list (obsToMod.h:88-107; call-site optimizer.cpp:620-630):
  * every pointer is a device pointer, the per-model tables (T_fms, sdfFrames, sdfs, pts) are device arrays of device pointers
- * built from the getters above. The handles are recovered from T_fms[m]; T_mcs[m] (optimizer.cpp:603-608) becomes the model's
- * camera->model transform. sdfFrames / sdfs / nSdfs / normalThresholds / dDebugNorm are accepted and not read (the reference
+ * built from the getters above. The handles are recovered from T_fms[m]; T_mcs[m] (optimizer.cpp:603-608), when not null, is the
+ * camera->model transform THIS LAUNCH uses for model m -- a kernel argument as in the reference: the models' own T_mc / T_cm are
+ * not changed. sdfFrames / sdfs / nSdfs / normalThresholds / dDebugNorm are accepted and not read (the reference
  * kernel does not read the last two either, SURVEY A-20). Blocking (small device->host copies of the tables). */
 int dartk_assoc_multi_tables(const float *d_vert, const float *d_norm, int width, int height, int nModels, const float *d_T_mcs,
                              const void *const *d_T_fms, const void *const *d_sdfFrames, const void *const *d_sdfs,
@@ -137,7 +138,8 @@ int dartk_ne_obs2mod(int dims, const float *d_vert, int width, int height, dartk
 /* NO COUNTERPART IN THE REFERENCE. dartk_ne_obs2mod for callers that cannot allocate (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc): same arguments, same kernels, same result, but the partial-system scratch
  * lives in a fixed device array inside the library instead of its hipMalloc'ed workspace, and the call performs no hipMalloc /
- * hipFree / allocating library call. Limits: dims <= 32 (the array holds 256 partial systems of that size, 561 KiB per GPU,
+ * hipFree / allocating library call. dartk_init(device) must have run on the current device (it resolves the array's device
+ * address; the entry point refuses a device it has not seen rather than initialise anything inside the call). Limits: dims <= 32 (the array holds 256 partial systems of that size, 561 KiB per GPU,
  * kept until the process ends); larger models are rejected with DARTK_ERR_INVALID. All calls on one GPU share the array: calls
  * that overlap on one GPU (two streams, two threads) race -- serialise them. */
 int dartk_ne_obs2mod_noalloc(int dims, const float *d_vert, int width, int height, dartk_model_t m, float huberDelta,

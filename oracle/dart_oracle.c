@@ -675,6 +675,59 @@ void orc_cull_unobservable(float *pred, int pw, int ph, const float *obs, int ow
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * sensor front end: depth -> vertices -> normals (the step before the path)
+ * ---------------------------------------------------------------------------------------------- */
+/* gpu_depthToVertices<float>, organized_point_cloud.cu:11-40. An out-of-range depth only clears .w (:36-38): x, y, z of
+ * that pixel keep what vertOut held before the call. */
+void orc_depth_to_vertices(const float *depth, float *vert, int width, int height, float ppx, float ppy, float flx,
+                           float fly, float rangeMin, float rangeMax) {
+    for (int v = 0; v < height; ++v) for (int u = 0; u < width; ++u) {
+        const int index = u + v * width;
+        const float d = depth[index];
+        float *o = vert + 4 * index;
+        if (d >= rangeMin && d <= rangeMax) {
+            o[0] = ((float)u - ppx) * (d / flx);   /* :30 (int - float promotes the int) */
+            o[1] = ((float)v - ppy) * (d / fly);   /* :31 */
+            o[2] = d;
+            o[3] = 1.0f;
+        } else {
+            o[3] = 0;
+        }
+    }
+}
+
+/* gpu_verticesToNormals, organized_point_cloud.cu:265-305: central differences over the 4-neighbourhood, a neighbour
+ * outside the image or with w == 0 replaced by the pixel itself (:286-292), n = cross(vY, vX) normalised, w = 1;
+ * invalid pixels and degenerate crosses (len2 == 0, NaN) give (0,0,0,0). */
+void orc_vertices_to_normals(const float *vert, float *norm, int width, int height) {
+    for (int y = 0; y < height; ++y) for (int x = 0; x < width; ++x) {
+        const int index = x + y * width;
+        const float *v = vert + 4 * index;
+        float *o = norm + 4 * index;
+        if (v[3] == 0) { o[0] = o[1] = o[2] = o[3] = 0; continue; }
+        const float *vL = vert + 4 * (x == 0 ? index : index - 1);
+        const float *vR = vert + 4 * (x == width - 1 ? index : index + 1);
+        const float *vU = vert + 4 * (y == 0 ? index : index - width);
+        const float *vD = vert + 4 * (y == height - 1 ? index : index + width);
+        if (vR[3] == 0) vR = v;
+        if (vL[3] == 0) vL = v;
+        if (vD[3] == 0) vD = v;
+        if (vU[3] == 0) vU = v;
+        const float vX[3] = {vR[0] - vL[0], vR[1] - vL[1], vR[2] - vL[2]};
+        const float vY[3] = {vD[0] - vU[0], vD[1] - vU[1], vD[2] - vU[2]};
+        /* helper_math.h cross(a,b) = (a.y b.z - a.z b.y, a.z b.x - a.x b.z, a.x b.y - a.y b.x) */
+        const float n[3] = {vY[1] * vX[2] - vY[2] * vX[1], vY[2] * vX[0] - vY[0] * vX[2], vY[0] * vX[1] - vY[1] * vX[0]};
+        const float len2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+        if (len2 > 0) {
+            const float invLen = 1.0f / sqrtf(len2);
+            o[0] = n[0] * invLen; o[1] = n[1] * invLen; o[2] = n[2] * invLen; o[3] = 1;
+        } else {
+            o[0] = o[1] = o[2] = o[3] = 0;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * observation SDF: splat + distance transform
  * ---------------------------------------------------------------------------------------------- */
 void orc_splat_obs_sdf(const float *vert, int width, int height, const float *T_cm, const orc_grid *g,

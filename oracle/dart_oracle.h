@@ -121,6 +121,11 @@ void orc_raycast_prediction(float flx, float fly, float ppx, float ppy, int widt
                             float levelSet, float *prediction);
 /* gpu_cullUnobservable, modToObs.cu:682-709 */
 void orc_cull_unobservable(float *pred, int pw, int ph, const float *obsVert, int ow, int oh);
+/* gpu_depthToVertices<float>, img_proc/organized_point_cloud.cu:11-40 (out-of-range depth: only .w is cleared) */
+void orc_depth_to_vertices(const float *depth, float *vert, int width, int height, float ppx, float ppy, float flx,
+                           float fly, float rangeMin, float rangeMax);
+/* gpu_verticesToNormals, img_proc/organized_point_cloud.cu:265-305 */
+void orc_vertices_to_normals(const float *vert, float *norm, int width, int height);
 /* gpu_splatObsSdf, modToObs.cu:403-441 (T_cm = model-to-camera) */
 void orc_splat_obs_sdf(const float *vert, int width, int height, const float *T_cm, const orc_grid *obsSdf,
                        float focalLength, float *data);

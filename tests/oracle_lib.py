@@ -228,6 +228,23 @@ def cull_unobservable(pred, obs):
     return pred
 
 
+def depth_to_vertices(depth, pp, fl, depth_range=(0.1, 5.0), out=None):
+    """orc_depth_to_vertices; `out` ([h, w, 4], updated in place and returned) carries what the vertex map held before."""
+    h, w = depth.shape
+    vert = np.zeros((h, w, 4), dtype=F) if out is None else out
+    assert vert.dtype == F and vert.flags.c_contiguous
+    lib().orc_depth_to_vertices(f(c32(depth)), f(vert), w, h, C.c_float(pp[0]), C.c_float(pp[1]), C.c_float(fl[0]), C.c_float(fl[1]),
+                                C.c_float(depth_range[0]), C.c_float(depth_range[1]))
+    return vert
+
+
+def vertices_to_normals(vert):
+    h, w = vert.shape[:2]
+    norm = np.zeros((h, w, 4), dtype=F)
+    lib().orc_vertices_to_normals(f(c32(vert)), f(norm), w, h)
+    return norm
+
+
 def splat_obs_sdf(vert, T_cm, obs_layout, focal_length=537.0):
     dim, off, res = obs_layout
     data = np.zeros((dim[2], dim[1], dim[0]), dtype=F)

@@ -109,3 +109,55 @@ def test_pointer_table_entry_points_match_handle_entry_points(gpu):
     # an array that belongs to no model is refused
     rc = L.dartk_count_self_intersections_tables(p_(tr.clouds[0]), 4, p_(vert), p_(vert), None, None, m0.n_sdfs, p_(tr.potentials[0]), _abi.iptr(c))
     assert rc == -1 and b"not a device array of a live dartk model" in L.dartk_last_error()
+
+
+@pytest.mark.gpu
+def test_assoc_multi_tables_T_mcs_is_an_argument_not_a_model_update(gpu):
+    """The reference's T_mcs is a kernel argument (obsToMod.h:88-107): it steers the launch and leaves the MirroredModel alone. Here:
+    the association with T_mcs != the models' poses equals the handle-based one with the models posed that way, and afterwards
+    T_mc, T_cm (its inverse) and get_transforms() of both models are what they were."""
+    sc = configs.config5(320, 180, 1)
+    tr = configs.make_multi_tracker(sc)
+    n = 2
+    for m, (T, a) in enumerate(sc.true):
+        tr.getPose(m).setTransformCameraToModel(T)
+        tr.getPose(m).getReducedArticulation()[:] = a
+        tr.updatePose(m)
+    _, vert, norm = synthetic_observation(tr.models, sc.width, sc.height, sc.fl, sc.pp)
+    h, w = vert.shape[:2]
+    thr, po, pn = [0.03, 0.03], [-0.03, -0.03], [[0, 0, 0], [0, 0, 0]]
+    # expected: the models at the start poses, through the handle-based entry point
+    for m, (T, a) in enumerate(sc.init):
+        tr.getPose(m).setTransformCameraToModel(T)
+        tr.updatePose(m)
+    pts, counts, dbg = D.error_and_data_association_multi(vert, norm, tr.models, thr, po, pn, debug=True)
+    T_arg = torch.from_numpy(np.stack([tr.getPose(m).getTransformCameraToModel() for m in range(n)]).astype(F)).to(gpu)
+    # the models go back to the true poses (same articulation: T_mcs replaces only T_mc), the start poses travel as T_mcs
+    for m, (T, a) in enumerate(sc.true):
+        tr.getPose(m).setTransformCameraToModel(T)
+        tr.updatePose(m)
+    before = [m.get_transforms() for m in tr.models]
+    pred_before = D.raycast_prediction(tr.models, tr.pred_fl, (F(tr.pred_width // 2), F(tr.pred_height // 2)), tr.pred_width, tr.pred_height).clone()
+    L = lib()
+    p_ = D._ptr
+    t_Tfm = _dev_ptr_table([L.dartk_model_device_T_fm(m.handle) for m in tr.models], gpu)
+    pts2 = [D.new_pts(h * w, gpu) for _ in range(n)]
+    t_pts = _dev_ptr_table([p.data_ptr() for p in pts2], gpu)
+    d_thr, d_po = torch.tensor(thr, dtype=torch.float32, device=gpu), torch.tensor(po, dtype=torch.float32, device=gpu)
+    d_pn = torch.zeros(6, dtype=torch.float32, device=gpu)
+    last = torch.zeros(n, dtype=torch.int32, device=gpu)
+    da = torch.empty((h, w), dtype=torch.int32, device=gpu)
+    check(L.dartk_assoc_multi_tables(p_(vert), p_(norm), w, h, n, p_(T_arg), p_(t_Tfm), None, None, None, p_(d_thr), None,
+                                     p_(d_po), p_(d_pn), p_(last), p_(t_pts), p_(da), None, None, D._stream()))
+    assert np.array_equal(last.cpu().numpy(), counts) and counts.min() > 100
+    assert np.array_equal(da.cpu().numpy(), dbg["da"].cpu().numpy())
+    # not the association of the models' own (true) poses
+    _, counts_true, dbg_true = D.error_and_data_association_multi(vert, norm, tr.models, thr, po, pn, debug=True)
+    assert not np.array_equal(dbg_true["da"].cpu().numpy(), da.cpu().numpy())
+    after = [m.get_transforms() for m in tr.models]
+    for m in range(n):
+        for x, y in zip(before[m], after[m]):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+    # T_cm users (ray-cast, pairwise intersection transforms) see the same pose as before the call
+    pred_after = D.raycast_prediction(tr.models, tr.pred_fl, (F(tr.pred_width // 2), F(tr.pred_height // 2)), tr.pred_width, tr.pred_height)
+    assert torch.equal(pred_after, pred_before) and int((pred_before[..., 2] != 0).sum()) > 100

@@ -25,6 +25,11 @@ def rel_err_blocks(got, ref, dims):
     return out
 
 
+def free_bytes():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
 def test_no_alloc_entry_matches_allocating_entry(gpu):
     m = scenes.articulated("allegro")
     dm = D.DeviceModel(m, model_id=0)
@@ -41,7 +46,10 @@ def test_no_alloc_entry_matches_allocating_entry(gpu):
         assert count > 1000
         out = torch.full((D.sys_len(m.dims),), float("nan"), dtype=torch.float32, device=gpu)
         ref = D.norm_eqns_obs_to_mod(v_d, dm, pts, count, huber_delta=0.02).cpu().numpy()
-        got = D.norm_eqns_obs_to_mod(v_d, dm, pts, count, huber_delta=0.02, result=out, no_alloc=True).cpu().numpy()
+        before = free_bytes()
+        got_d = D.norm_eqns_obs_to_mod(v_d, dm, pts, count, huber_delta=0.02, result=out, no_alloc=True)
+        assert free_bytes() == before, "the no-allocation entry point changed the device's free memory"
+        got = got_d.cpu().numpy()
         tiles = (count + 127) // 128
         err = rel_err_blocks(got, ref, m.dims)
         print("%dx%d: %d points, %d tiles: no-alloc vs allocating entry %.2e%s" % (w, h, count, tiles, err, " (bit-exact)" if np.array_equal(got.view(np.int32), ref.view(np.int32)) else ""))
@@ -58,3 +66,28 @@ def test_no_alloc_entry_matches_allocating_entry(gpu):
     # a system beyond the fixed array's 32 dimensions is refused with a clear error 
     rc = lib().dartk_ne_obs2mod_noalloc(40, _ptr(v_d), 96, 64, dm.handle, 0.02, _ptr(pts), count, _ptr(out), _stream())
     assert rc == -1 and b"at most 32 dimensions" in lib().dartk_last_error()
+
+
+def test_no_alloc_entry_small_system_uses_the_same_kernel(gpu):
+    """A packed system of at most 128 entries (dims <= 14): dartk_ne_obs2mod runs the one-output-per-thread instantiation, and so
+    does the no-allocation entry -- bit-identical while both cut the list into the same workgroups. The rigid sphere (6 dims,
+    28 entries) and Barrett (6 + 8 dims, 120 entries)."""
+    for name, n_min in (("sphere", 300), ("barrett", 300)):
+        m = scenes.sphere() if name == "sphere" else scenes.articulated(name)
+        dm = D.DeviceModel(m, model_id=0)
+        joints = scenes.random_joints(m, 5) if m.n_joints else np.zeros(0, dtype=F)
+        T_mc = scenes.random_T(22, base=(0, 0, -0.5))
+        dm.set_pose(T_mc, joints)
+        _, T_mf, _, _ = dm.get_transforms()
+        vert = scenes.points_near_model(m, T_mf, se3.invert(T_mc), 128, 96, 8)
+        v_d = torch.from_numpy(vert).to(gpu)
+        pts, count, _ = D.error_and_data_association(v_d, torch.zeros_like(v_d), dm, dist_threshold=0.05)
+        assert count > n_min and (count + 127) // 128 <= 256
+        ref = D.norm_eqns_obs_to_mod(v_d, dm, pts, count, huber_delta=0.02).cpu().numpy()
+        out = torch.full((D.sys_len(m.dims),), float("nan"), dtype=torch.float32, device=gpu)
+        before = free_bytes()
+        got_d = D.norm_eqns_obs_to_mod(v_d, dm, pts, count, huber_delta=0.02, result=out, no_alloc=True)
+        assert free_bytes() == before
+        got = got_d.cpu().numpy()
+        assert np.isfinite(got).all() and np.abs(ref).max() > 0
+        assert np.array_equal(got.view(np.int32), ref.view(np.int32)), (name, m.dims, rel_err_blocks(got, ref, m.dims))
