@@ -134,6 +134,26 @@ def tr_slab_floats(tr):
     return total, min(tiles, want) * S(D_)
 
 
+def spawn_ranks(args):
+    """Launch `--gpus N` ranks of this script on this node (one process per GPU, RCCL between them) and return the launcher's
+    exit code. Nothing here touches the GPU: torch.cuda.device_count() does not initialise it."""
+    import socket
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()
+    if not args.rehearse_on_one_gpu and n_dev < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible (--rehearse-on-one-gpu runs every rank on cuda:0 over gloo: "
+                         "a test of the sharding code, not a measurement)\n" % (args.gpus, n_dev))
+        return 2
+    with socket.socket() as sk:      # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +176,14 @@ def main():
                          "exercises the sharding / gather / max-over-ranks code of the multi-GPU launch, the numbers mean nothing")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this script under torch.distributed.run -- a
+    # child process, started before anything in this one touches the GPU -- and leave with its exit code. Rank 0 of the
+    # children prints the JSON line. Under a launcher (WORLD_SIZE set, the driver's form) this process IS a rank.
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
     import torch
     import torch.distributed as dist
     from dart_amd import configs, device as D, sharding
@@ -165,6 +193,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); start it as `python bench.py --gpus N` or "
+                 "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
+    n_dev = torch.cuda.device_count()       # (counting devices does not initialise the GPU)
+    if not args.rehearse_on_one_gpu and n_dev < world:
+        sys.exit("bench.py: %d rank(s) need %d GPUs, %d visible (--rehearse-on-one-gpu puts every rank on cuda:0 over gloo to "
+                 "exercise the sharding code on a 1-GPU box)" % (world, world, n_dev))
     distributed = world > 1
     if args.rehearse_on_one_gpu:
         local_rank = 0
