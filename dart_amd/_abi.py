@@ -193,6 +193,7 @@ def _load(path):
         "dartk_raycast_prediction": [C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp],
         "dartk_cull_unobservable": [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp],
         "dartk_obs_sdf_build": [vp, C.c_int, C.c_int, vp, C.c_float, vp],
+        "dartk_splat_obs_sdf_zeros": [vp, C.c_int, C.c_int, c_float_p, vp, C.c_float, vp],
         "dartk_distance_transform_3d": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp],
         "dartk_signed_distance_transform_3d": [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp],
         "dartk_ne_mod2obs": [C.c_int, vp, C.c_int, C.c_int, vp, c_float_p, vp, vp, vp],

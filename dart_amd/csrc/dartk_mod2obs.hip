@@ -962,6 +962,27 @@ int dartk_obs_sdf_build(const float *d_vert, int width, int height, dartk_model_
     return gn_obs_sdf_build(d_vert, width, height, mod, focalLength, as_stream(stream));
 }
 
+static int upload_T(const float *h_T, float **d_T, hipStream_t st);
+
+int dartk_splat_obs_sdf_zeros(const float *d_vert, int width, int height, const float *h_T_cm, dartk_model_t h, float focalLength,
+                              void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_vert && h_T_cm, "dartk_splat_obs_sdf_zeros: null argument");
+    DARTK_REQUIRE(mod->obsVoxels > 0, "model has no observation SDF");
+    DARTK_REQUIRE(width > 0 && height > 0, "bad map size");
+    hipStream_t st = as_stream(stream);
+    float *d_T = nullptr;
+    int rc = upload_T(h_T_cm, &d_T, st);
+    if (rc) return rc;
+    ModelView m = mod->v;
+    m.T_cm = d_T;               // the argument steers this launch, the model's own pose stays as it is (T_cm by reference there)
+    const int n = (int)mod->obsVoxels;
+    hipLaunchKernelGGL(splat_obs_sdf_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, st, (const float4 *)d_vert, width, height, m, focalLength,
+                       FrameBatch{1, 0, 0, 0, 0, 0, 0, 0}, mod->v.obsData, (float *)nullptr);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+
 static int upload_T(const float *h_T, float **d_T, hipStream_t st) {
     Workspace *ws;
     int rc = get_workspace(&ws);

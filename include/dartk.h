@@ -168,9 +168,17 @@ int dartk_cull_unobservable(float *d_pred, int predWidth, int predHeight, const 
                             int obsHeight, void *stream);
 /* Optimizer::generateObsSdfSplatZeroAndDistanceTransform, optimizer.cpp:168-219 = splatObsSdfZeros
  * (modToObs.cu:990-1008) + distanceTransform3D<float,true> (distance_transforms.cu:434-458) + copy back.
- * Uses the model's current T_cm. Obs-SDF dims must be multiples of (8,8,4) (modToObs.cu:998-999). */
+ * Uses the model's current T_cm. Any obs-SDF dims: the reference's splat grid has no ceil and needs multiples of (8,8,4)
+ * (modToObs.cu:998-999); the grids here are ceil-divided. */
 int dartk_obs_sdf_build(const float *d_vert, int width, int height, dartk_model_t m, float focalLength,
                         void *stream);
+/* splatObsSdfZeros alone, modToObs.h:68-74 / modToObs.cu:990-1008 (kernel :403-441): writes 0 (behind the observed surface) /
+ * 500 (no observation) / 1000 (free or outside the image) into the model's observation SDF (dartk_model_obs_sdf_data) for the
+ * given model->camera transform h_T_cm (host SE3, by reference in the reference; the model's pose is not changed). The
+ * reference's caller follows it with distanceTransform3D<float,true> into a scratch volume and a copy back
+ * (optimizer.cpp:205-215): dartk_distance_transform_3d. dartk_obs_sdf_build does all three in one call. */
+int dartk_splat_obs_sdf_zeros(const float *d_vert, int width, int height, const float *h_T_cm, dartk_model_t m, float focalLength,
+                              void *stream);
 /* distanceTransform3D / signedDistanceTransform3D on device buffers (distance_transforms.h:16-29);
  * d_in is clobbered as in the reference. */
 int dartk_distance_transform_3d(float *d_in, float *d_out, int width, int height, int depth, int takeSqrt,

@@ -105,6 +105,35 @@ def test_obs_sdf_build(gpu, name):
     assert np.array_equal(got.view(np.int32), ref.view(np.int32))
 
 
+def test_splat_obs_sdf_zeros_alone_with_its_own_transform(gpu):
+    """splatObsSdfZeros as the reference declares it (modToObs.h:68-74): T_cm is an argument; the model's pose stays. Followed by
+    the caller's distanceTransform3D (optimizer.cpp:205-215) it gives what dartk_obs_sdf_build gives at that pose."""
+    from dart_amd._abi import check, lib, fptr
+    w, h = 320, 240
+    m, om, dm, T_mc, T_mf, T_fm, layout = posed("allegro", 6, gpu, obs=True, z=0.5)
+    fl, pp = (537.0 / 2, 537.0 / 2), (w / 2, h / 2)
+    obs = D.raycast_prediction([dm], fl, pp, w, h).cpu().numpy()
+    obs[..., 3] = (obs[..., 2] != 0).astype(F)
+    obs[obs[..., 3] == 0] = 0
+    obs_d = torch.from_numpy(obs).to(gpu)
+    T_other = se3.mul(se3.invert(T_mc), se3.exp(np.array([0.01, -0.02, 0.015, 0.05, -0.03, 0.04], dtype=F)))     # not the model's T_cm
+    before = dm.get_transforms()
+    check(lib().dartk_splat_obs_sdf_zeros(D._ptr(obs_d), w, h, fptr(np.ascontiguousarray(T_other, dtype=F)), dm.handle, fl[0], D._stream()))
+    got = D.obs_sdf_numpy(dm)
+    ref = O.splat_obs_sdf(obs, T_other, layout, focal_length=fl[0])
+    assert np.array_equal(got.view(np.int32), ref.view(np.int32)) and (ref == 0).sum() > 50
+    assert not np.array_equal(ref, O.splat_obs_sdf(obs, se3.invert(T_mc), layout, focal_length=fl[0]))
+    assert all(np.array_equal(a, b) for a, b in zip(before, dm.get_transforms()))
+    # the caller's next two steps: distance transform into a scratch volume, copy back
+    n = got.size
+    scratch = torch.empty(n, dtype=torch.float32, device=gpu)
+    ptr = lib().dartk_model_obs_sdf_data(dm.handle)
+    import ctypes as C
+    check(lib().dartk_distance_transform_3d(C.c_void_p(ptr), D._ptr(scratch), layout[0][0], layout[0][1], layout[0][2], 1, D._stream()))
+    dt_ref = O.distance_transform_3d(ref, take_sqrt=True)
+    assert np.array_equal(scratch.cpu().numpy().reshape(dt_ref.shape).view(np.int32), dt_ref.view(np.int32))
+
+
 @pytest.mark.parametrize("name", ["allegro", "left_hand"])
 def test_mod2obs_normal_equations(gpu, name):
     w, h = 160, 120
