@@ -42,19 +42,90 @@ HBM_PEAK_GBS = 8000.0
 TRACE_BYTES_PER_PAIR = 8        # ray-cast trace record per traced (prediction pixel, SDF) pair: {detection t, hit t}
 PROF_NAMES = ["obs_sdf_build", "raycast_trace_kernel", "fused_obs2mod_kernel", "ne_mod2obs_kernel", "ne_self_intersection_kernel",
               "gn_solve_single_kernel", "raycast_replay_kernel", "valid_pixel_compaction", "gn_reduce_kernel",
-              "noobs_terms_kernel<intersection>", "noobs_solve_kernel", "noobs_terms_kernel<priors>"]
+              "noobs_terms_kernel<intersection>", "noobs_solve_kernel", "noobs_terms_kernel<priors>", "assoc_multi_kernel"]
 O_ASSOC, O_ASSOC_GRAD, O_NE_O2M, O_RAYCAST, O_M2O, O_INTER, O_PRIOR = 1, 2, 3, 4, 5, 6, 7
-N_CLASSES = 12
-# PMC HBM traffic per launch (bytes) measured with rocprofv3 --pmc, corrected as MI355X_MICROARCH.md prescribes; filled in
-# from profiles/ (see profiles/README.md). None = not collected for that kernel.
-PMC_TRAFFIC = {}
-_pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-if os.path.exists(_pmc_path):
-    with open(_pmc_path) as _f:
-        PMC_TRAFFIC = json.load(_f)
+N_CLASSES = 13
+
+
+def _profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return {}
+
+
+# What the committed rocprofv3 passes of THIS bench command measured (profiles/README.md says which pass wrote which file);
+# the live run prices its own HIP-event durations and prints these beside them. Empty = not collected.
+PMC_TRAFFIC = _profile_json("pmc_traffic.json")                 # HBM bytes per launch (FETCH_SIZE / WRITE_SIZE passes, corrected)
+PMC_TRAFFIC_BATCH = _profile_json("pmc_traffic_batch.json")     # the same for the 64-frame launches of the config-5 batch
+ROCPROF = _profile_json("kernel_durations.json")                # --kernel-trace: calls / median / average duration per kernel
+L2_RATES = _profile_json("l2_hit_rate.json")                    # TCC_HIT / MISS / REQ pass
+LIMITERS = _profile_json("kernel_limiters.json")                # what the counters say bounds each kernel (+ the evidence)
+# bench kernel class -> (kernel name in the rocprof tables, regular expression on its template arguments or None)
+ROCPROF_KERNELS = {
+    "trace_and_obs2mod_kernel": [("trace_and_obs2mod_kernel", None)],
+    "fused_obs2mod_kernel": [("fused_obs2mod_kernel", None), ("ne_obs2mod_kernel", None)],
+    "raycast_trace_kernel": [("raycast_trace_kernel", None)],
+    "ne_mod2obs_kernel": [("ne_mod2obs_kernel", r"(true$)|(@batch)")],      # single frame: the instantiation with the fused replay (config 2)
+    "gn_reduce_kernel": [("gn_reduce_kernel", None)],
+    "gn_solve_single_kernel": [("gn_solve_single_kernel", None)],
+    "noobs_terms_kernel<priors>": [("noobs_terms_kernel", r"^\d+, [234]")],
+    "noobs_terms_kernel<intersection>": [("noobs_terms_kernel", r"^\d+, [01]")],
+    "noobs_solve_kernel": [("noobs_solve_kernel", None)],
+    "assoc_multi_kernel": [("assoc_multi_kernel", None)],
+    "raycast_replay_kernel": [("raycast_replay_multi_rows_kernel", None), ("raycast_replay_multi_kernel", None), ("raycast_replay_kernel", None)],
+    "ne_self_intersection_kernel": [("ne_self_intersection_kernel", None), ("ne_intersection_kernel", None)],
+    "multi_solve_kernel": [("multi_solve_kernel", None)],
+}
+
+
+def rocprof_stats(kernel, batch, retry=True):
+    """calls / median / average launch duration of `kernel` (a ROCPROF_KERNELS class) in the committed rocprofv3 kernel trace;
+    batch: the launches with more than one grid row (frames / candidates) or the single-row ones. None when not collected."""
+    import re
+    tot_calls, avg_sum, meds = 0, 0.0, []
+    for base, targs in ROCPROF_KERNELS.get(kernel, [(kernel, None)]):
+        for key, v in ROCPROF.items():
+            name, is_batch = (key[:-6], True) if key.endswith("@batch") else (key, False)
+            if is_batch != batch:
+                continue
+            b, _, rest = name.partition("<")
+            if b != base or (targs and not re.search(targs, rest.rstrip(">") + ("@batch" if is_batch else ""))):
+                continue
+            tot_calls += v["calls"]
+            avg_sum += v["avg_us"] * v["calls"]
+            meds.append((v["median_us"], v["calls"]))
+    if not tot_calls:
+        # kernels whose second grid dimension is not a frame (gn_reduce_kernel: term; noobs_solve_kernel: candidates in x)
+        return rocprof_stats(kernel, not batch, False) if retry else None
+    return {"calls": tot_calls, "avg_us": round(avg_sum / tot_calls, 2),
+            "median_us": round(sum(m * c for m, c in meds) / tot_calls, 2), "source": "profiles/kernel_durations.json"}
+
+
+def l2_hit_rate(kernel):
+    """launch-weighted L2 (TCC) hit rate of the kernel class in the committed counter pass (all its instantiations)"""
+    hit, n = 0.0, 0
+    for base, _ in ROCPROF_KERNELS.get(kernel, [(kernel, None)]):
+        for key, v in L2_RATES.items():
+            if key.partition("<")[0] == base:
+                hit += v["hit_rate"] * v["launches"]
+                n += v["launches"]
+    return round(hit / n, 4) if n else None
+
+
+def pmc_traffic(kernel, table):
+    """HBM bytes per launch of the kernel class in a pmc_traffic*.json table (keyed by kernel name without template arguments)"""
+    if kernel in table:
+        return table[kernel]
+    for base, _ in ROCPROF_KERNELS.get(kernel, []):
+        if base in table:
+            return table[base]
+    return None
 
 
 def prof_collect(lib, fptr, iptr, check, fn, reps):
+    """HIP-event durations per kernel class over `reps` calls of fn: (us per launch, us per call, launches per call)"""
     check(lib.dartk_profile_begin())
     for _ in range(reps):
         fn()
@@ -63,7 +134,8 @@ def prof_collect(lib, fptr, iptr, check, fn, reps):
     check(lib.dartk_profile_end(fptr(ms), iptr(cnt)))
     per_launch_us = {PROF_NAMES[i]: float(1000.0 * ms[i] / cnt[i]) for i in range(N_CLASSES) if cnt[i]}
     per_step_us = {PROF_NAMES[i]: float(1000.0 * ms[i] / reps) for i in range(N_CLASSES) if cnt[i]}
-    return per_launch_us, per_step_us
+    launches = {PROF_NAMES[i]: float(cnt[i]) / reps for i in range(N_CLASSES) if cnt[i]}
+    return per_launch_us, per_step_us, launches
 
 
 def cpu_model_name():
@@ -95,19 +167,44 @@ def count_lookups(fn):
     return [int(v) for v in cnt]
 
 
-def roofline_entry(name, bytes_per_launch, lookups_per_launch, per_launch_us):
-    """One kernel's roofline figures. achieved = algorithmic bytes of the work performed / measured duration."""
+def roofline_entry(name, bytes_per_launch, lookups_per_launch, per_launch_us, batch=False, traffic_table=None):
+    """One kernel's roofline figures. achieved = algorithmic bytes of the work performed / the launch duration measured live with
+    HIP events on the launch stream. `bound` names the roof the fraction is priced against (HBM bandwidth: every kernel of this
+    path moves bytes, none is a GEMM); `limiter` says what the committed counter passes show actually bounds the kernel
+    (latency of a dependent-load chain, instruction issue, or HBM), with the evidence. `rocprof`: the same kernel's duration in
+    the committed rocprofv3 --kernel-trace pass of this command (two event records per launch make the live figure 2-4 us
+    longer); `frac_rocprof` prices the same bytes with that median."""
     us = per_launch_us[name]
     ach = bytes_per_launch / (us * 1e-6) / 1e9
-    traffic = PMC_TRAFFIC.get(name)
-    e = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    traffic = pmc_traffic(name, PMC_TRAFFIC if traffic_table is None else traffic_table)
+    lim = LIMITERS.get(name + ("@batch" if batch and (name + "@batch") in LIMITERS else ""), {})
+    rp = rocprof_stats(name, batch)
+    e = {"bound": "hbm", "limiter": lim.get("limiter"), "limiter_evidence": lim.get("evidence"), "kernel": name,
+         "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
          "frac_hbm": round(traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
-         "l2_gather_GBs": round(32.0 * lookups_per_launch / (us * 1e-6) / 1e9, 2),
+         "l2_gather_GBs": round(32.0 * lookups_per_launch / (us * 1e-6) / 1e9, 2), "l2_hit_rate": l2_hit_rate(name),
          "algorithmic_bytes_per_launch": round(bytes_per_launch), "lookups_per_launch": round(lookups_per_launch),
-         "avg_launch_us": round(us, 2)}
+         "avg_launch_us": round(us, 2), "rocprof": rp,
+         "frac_rocprof": round(bytes_per_launch / (rp["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if rp else None}
     assert e["frac"] <= 1.0, "a roofline fraction above 1 means the priced work is not the work performed: %r" % e
     return e
+
+
+def per_step_from_rocprof(launches, batch, chain, ms_per_step):
+    """us per step per kernel class = committed rocprofv3 median x launches per step (live launch counts); `chain` lists the classes
+    that run back to back on the caller's stream: their sum must fit into the measured step."""
+    out = {}
+    for k, n in launches.items():
+        rp = rocprof_stats(k, batch)
+        if rp:
+            out[k] = round(rp["median_us"] * n, 2)
+    if not out:
+        return None
+    s = sum(out.get(k, 0.0) for k in chain)
+    return {"source": "rocprofv3 --kernel-trace medians (profiles/kernel_durations.json) x live launch counts", "us": out,
+            "critical_chain": list(chain), "critical_chain_sum_us": round(s, 2), "ms_per_step_us": round(1000.0 * ms_per_step, 2),
+            "chain_fits_step": bool(s <= 1000.0 * ms_per_step)}
 
 
 def tr_slab_floats(tr):
@@ -281,11 +378,31 @@ def main():
         repeats = {"n": len(rep_all), "ms_per_step_median": round(float(np.median(rep_all)), 4), "ms_per_step_min": round(rep_all[0], 4),
                    "ms_per_step_max": round(rep_all[-1], 4), "value_median": round(world * iters / (float(np.median(rep_all)) * 1e-3), 1)}
 
+    # the same workload at the reference's default normal gate (normThreshold -0.1, optimization.h:44): with the reference's own
+    # normals and nPred = -gradient the gate drops most camera-facing points (DESIGN.md section 4 iii), so it does LESS work than
+    # the headline (gate off); reported beside it
+    value_default_gate = None
+    if not args.no_tracking and args.norm_threshold is None:
+        keep_thr = sc.opts.normThreshold
+        sc.opts.normThreshold = -0.1
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        tg0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        barrier()
+        g_el = max_over_ranks(time.perf_counter() - tg0)
+        step(debug=True)
+        value_default_gate = {"value": round(world * n_steps * iters / g_el, 2), "normThreshold": -0.1, "ms_per_step": round(1000.0 * g_el / max(n_steps, 1), 4),
+                              "associated_per_iter": float(opt.iter_info.cpu().numpy()[:, 3].mean())}
+        sc.opts.normThreshold = keep_thr
+
     roofline = None
     cpu_baseline = None
     if rank == 0 and not args.no_tracking:
         import oracle_lib as O
-        per_launch_us, per_step_us = prof_collect(lib(), fptr, iptr, check, step, args.steps)
+        per_launch_us, per_step_us, launches = prof_collect(lib(), fptr, iptr, check, step, args.steps)
         # lookups the kernels perform in one step (device counters of the diagnostic library, same inputs, same poses)
         cnt = count_lookups(lambda: step(debug=True))
         om = O.OModel(sc.host_model, 0, sc.obs_layout)
@@ -323,13 +440,18 @@ def main():
             lk[U] = lk.pop("raycast_trace_kernel") + lk.pop("fused_obs2mod_kernel")
             per_launch_us[U] = per_launch_us.pop("raycast_trace_kernel")
             per_step_us[U] = per_step_us.pop("raycast_trace_kernel")
+            launches[U] = launches.pop("raycast_trace_kernel")
         cands = {k: v for k, v in per_step_us.items() if k in bytes_per_launch}
         name = max(cands, key=cands.get)
         roofline = roofline_entry(name, bytes_per_launch[name], lk.get(name, 0.0), per_launch_us)
         it_bytes = sum(bytes_per_launch[k] for k in ("fused_obs2mod_kernel", "raycast_trace_kernel", "trace_and_obs2mod_kernel",
                                                      "ne_mod2obs_kernel", "gn_reduce_kernel", "gn_solve_single_kernel") if k in bytes_per_launch)
+        chain = [k for k in ("trace_and_obs2mod_kernel", "raycast_trace_kernel", "ne_mod2obs_kernel", "gn_reduce_kernel", "gn_solve_single_kernel")
+                 if k in launches]
         roofline.update({
-            "per_step_us": {k: round(v, 2) for k, v in per_step_us.items()},
+            "per_step_us": per_step_from_rocprof(launches, False, chain, elapsed / max(n_steps, 1)),
+            "per_step_us_events": {k: round(v, 2) for k, v in per_step_us.items()},
+            "launches_per_step": {k: round(v, 2) for k, v in launches.items()},
             "per_kernel": {k: roofline_entry(k, bytes_per_launch[k], lk.get(k, 0.0), per_launch_us) for k in bytes_per_launch if k in per_launch_us},
             "whole_iteration": {"algorithmic_bytes": round(it_bytes), "achieved_GBs": round(it_bytes / (elapsed / max(n_steps * iters, 1)) / 1e9, 2),
                                 "frac": round(it_bytes / (elapsed / max(n_steps * iters, 1)) / 1e9 / HBM_PEAK_GBS, 5)},
@@ -339,7 +461,9 @@ def main():
                                                       "raycast_march": cnt[4] / iters, "mod2obs": cnt[5] / iters}},
             "note": "latency-bound at batch 1: one frame's working set (SDFs L2/MALL-resident) cannot approach the HBM roof; an "
                     "iteration is four kernels back to back on one stream (trace + obs->mod in one launch, mod->obs, reduce, solve), "
-                    "the observation-SDF build of the call runs beside the first of them on a second stream"})
+                    "the observation-SDF build of the call runs beside the first of them on a second stream. per_step_us_events: HIP "
+                    "events (two records per launch stretch every kernel by 2-4 us, so their sum exceeds the step); per_step_us: the "
+                    "committed rocprofv3 medians"})
         if not args.no_cpu_baseline:
             nthr = cpu_threads(args)
 
@@ -388,7 +512,7 @@ def main():
         if rank == 0:
             import oracle_lib as O
             best = sharding.best_candidates(full_e, 5)
-            per_launch_us, per_step_us = prof_collect(lib(), fptr, iptr, check, grefine, 1)
+            per_launch_us, per_step_us, launches = prof_collect(lib(), fptr, iptr, check, grefine, 1)
             # algorithmic bytes of one terms-kernel launch (contact priors + intersection) with the lookups the kernels
             # perform, counted by the diagnostic library on a sample of this rank's candidates (2 iterations + getError = 3
             # passes of every term kernel per candidate)
@@ -417,9 +541,12 @@ def main():
                                 K_I: (16.0 * Cn + 32.0 * lk_inter + 4.0 * slab_inter + 3 * pose_bytes) * len(idx) / 3.0}
             lk_launch = {K_P: lk_prior * len(idx), K_I: lk_inter * len(idx) / 3.0}
             g_name = max((K_I, K_P), key=lambda k: per_step_us.get(k, 0.0))
-            g_roof = roofline_entry(g_name, bytes_per_launch[g_name], lk_launch[g_name], per_launch_us)
-            g_roof.update({"per_step_us": {k: round(v, 2) for k, v in per_step_us.items()},
-                           "per_kernel": {k: roofline_entry(k, bytes_per_launch[k], lk_launch[k], per_launch_us) for k in bytes_per_launch if k in per_launch_us},
+            g_roof = roofline_entry(g_name, bytes_per_launch[g_name], lk_launch[g_name], per_launch_us, batch=True)
+            g_roof.update({"per_step_us": per_step_from_rocprof(launches, True, [k for k in (K_I, K_P, "noobs_solve_kernel") if k in launches],
+                                                                g_elapsed / args.grasp_steps),
+                           "per_step_us_events": {k: round(v, 2) for k, v in per_step_us.items()},
+                           "per_kernel": {k: roofline_entry(k, bytes_per_launch[k], lk_launch[k], per_launch_us, batch=True)
+                                          for k in bytes_per_launch if k in per_launch_us},
                            "lookups_performed_per_candidate_per_pass": {"intersection": lk_inter, "priors": lk_prior},
                            "note": "the term kernels are instruction-issue bound (sphere / box rejects and exact bound tests per "
                                    "(point, SDF) pair) and their SDF working set is L2-resident: neither HBM nor gather bandwidth "
@@ -503,11 +630,90 @@ def main():
                 mtr.optimizePosesDevice(mvert[k], mnorm[k])
             torch.cuda.synchronize()
             single_its = n_s * m_iters / (time.perf_counter() - ts0)
+            # ---- roofline of this leg: HIP-event durations of one batch step with the three chains on ONE stream (side by side
+            # on three streams every kernel's duration is stretched by the others and says nothing), the lookups its kernels
+            # perform counted by the diagnostic library on a sample of the frames, algorithmic bytes per kernel class and step
+            import oracle_lib as O
+            nF = len(f_idx)
+            os.environ["DARTK_MULTI_ONE_STREAM"] = "1"
+            try:
+                mb = lambda: mtr.optimizePosesBatch(mvert, mnorm, mT0_d, ma0_d)      # noqa: E731
+                m_launch_us, m_step_us, m_launches = prof_collect(lib(), fptr, iptr, check, mb, 1)
+            finally:
+                del os.environ["DARTK_MULTI_ONE_STREAM"]
+            n_c = min(nF, 8)
+            mcnt = count_lookups(lambda: (mtr.optimizePosesBatch(mvert[:n_c], mnorm[:n_c], mT0_d[:n_c], ma0_d[:n_c]), torch.cuda.synchronize()))
+            mtr.optimizePosesBatch(mvert[:n_c], mnorm[:n_c], mT0_d[:n_c], ma0_d[:n_c], debug=True)
+            minfo = mtr.iteration_summaries            # [n_c, iters, nModels, 8]
+            per_fi = 1.0 / (n_c * m_iters)             # per frame and iteration
+            V = float((mvert[:n_c, :, :, 3] > 0).sum().item()) / n_c
+            N_a = float(minfo[:, :, :, 3].sum()) * per_fi
+            N_p = float(minfo[:, :, :, 4].sum()) * per_fi
+            rec = mcnt[0] * per_fi
+            lk5 = {"assoc_multi_kernel": mcnt[1] * per_fi, "fused_obs2mod_kernel": mcnt[3] * per_fi, "raycast_trace_kernel": mcnt[4] * per_fi,
+                   "ne_mod2obs_kernel": mcnt[5] * per_fi, "ne_self_intersection_kernel": mcnt[6] * per_fi}
+            Cn = float(sum(int(c.shape[0]) for c in mtr.clouds) + int(mtr.clouds[0].shape[0]))     # hand cloud: self + pairwise
+            # bytes per frame and iteration (SURVEY 8d with the lookups PERFORMED); the association's 16 B per valid pixel are read
+            # from the vertex map once per call and listed (4 B index), then every iteration walks the list
+            b5 = {"assoc_multi_kernel": 16.0 * V / m_iters + 20.0 * V + 32.0 * lk5["assoc_multi_kernel"] + 12.0 * N_a,
+                  "fused_obs2mod_kernel": 28.0 * N_a + 32.0 * lk5["fused_obs2mod_kernel"],
+                  "raycast_trace_kernel": 32.0 * lk5["raycast_trace_kernel"] + float(TRACE_BYTES_PER_PAIR) * rec,
+                  "raycast_replay_kernel": float(TRACE_BYTES_PER_PAIR) * rec + 16.0 * N_p,
+                  "ne_mod2obs_kernel": 16.0 * N_p * 2 + 32.0 * lk5["ne_mod2obs_kernel"],
+                  "ne_self_intersection_kernel": 16.0 * Cn + 32.0 * lk5["ne_self_intersection_kernel"]}
+            ents = {}
+            for k in b5:
+                if k not in m_launch_us:
+                    continue
+                n_l = m_launches[k]
+                ents[k] = roofline_entry(k, b5[k] * nF * m_iters / n_l, lk5.get(k, 0.0) * nF * m_iters / n_l, m_launch_us, batch=True,
+                                         traffic_table=PMC_TRAFFIC_BATCH)
+            m_roof = None
+            if ents:
+                dom = max(ents, key=lambda k: m_step_us.get(k, 0.0))
+                m_roof = dict(ents[dom])
+                it_b = sum(b5[k] for k in ents) * nF * m_iters
+                m_roof.update({
+                    "per_step_us": per_step_from_rocprof(m_launches, True, [], m_elapsed / args.multi_steps),
+                    "per_step_us_events": {k: round(v, 2) for k, v in m_step_us.items()},
+                    "launches_per_step": {k: round(v, 2) for k, v in m_launches.items()},
+                    "per_kernel": ents,
+                    "whole_step": {"algorithmic_bytes": round(it_b), "achieved_GBs": round(it_b / (m_elapsed / args.multi_steps) / 1e9, 2),
+                                   "frac": round(it_b / (m_elapsed / args.multi_steps) / 1e9 / HBM_PEAK_GBS, 5)},
+                    "counts_per_frame_and_iteration": {"valid_pixels": V, "associated": N_a, "predicted": N_p, "trace_records": rec,
+                                                       "lookups_performed": lk5, "sample_frames": n_c},
+                    "note": "event durations from one batch step with the loop's three chains on one stream (DARTK_MULTI_ONE_STREAM); "
+                            "the timed steps run them side by side on three streams, so the summed durations exceed the step; "
+                            "a launch covers a chunk of up to 64 frames"})
+            # ---- CPU baseline of this leg: the oracle's Optimizer::optimizePoses loop on the same frames (host copies of the maps)
+            m_cpu = None
+            if not args.no_cpu_baseline:
+                nthr = cpu_threads(args)
+                n_cpu = min(nF, 3)
+                v_h = [mvert[k].cpu().numpy() for k in range(n_cpu)]
+                n_h = [mnorm[k].cpu().numpy() for k in range(n_cpu)]
+
+                def cpu_frames(threads, n):
+                    O.set_threads(threads)
+                    tc0 = time.perf_counter()
+                    for k in range(n):
+                        kk = k % n_cpu
+                        O.optimize_poses(mtr, v_h[kk], n_h[kk], [mT0[kk, 0], mT0[kk, 1]], [ma0[kk], np.zeros(0, dtype=np.float32)])
+                    dt_ = time.perf_counter() - tc0
+                    O.set_threads(1)
+                    return n * m_iters / dt_
+                one = cpu_frames(1, 1)
+                many = cpu_frames(nthr, max(n_cpu, min(12, int(4 * one)) or 1))
+                smp = "frames x %d iterations (obs-SDF build + loop) of the same 1280x720 two-model workload, CPU oracle" % m_iters
+                m_cpu = {"value": round(many, 3), "unit": "GN iterations/s", "cores": nthr, "kind": "port", "cpu_model": cpu_model_name(),
+                         "sample": "%s, %d threads (OpenMP over pixels / rays / points)" % (smp, nthr),
+                         "single_thread": {"value": round(one, 3), "cores": 1, "sample": "1 %s, 1 thread" % smp}}
             multi = {"metric": "multi-model tracking, batch of independent frames (dartk_optimize_poses_batch)", "unit": "GN iterations/s",
                      "value": round(n_frames * args.multi_steps * m_iters / m_elapsed, 2),
                      "frames_per_s": round(n_frames * args.multi_steps / m_elapsed, 2), "scaling": "strong", "n_frames": n_frames,
                      "frames_per_gpu": len(f_idx), "steps": args.multi_steps, "ms_per_step": round(1000.0 * m_elapsed / args.multi_steps, 3),
-                     "iterations_per_step": m_iters, "single_frame_loop_GN_its": round(single_its, 2),
+                     "iterations_per_step": m_iters, "single_frame_loop_GN_its": round(single_its, 2), "dtype": "f32", "data": "synthetic",
+                     "roofline": m_roof, "cpu_baseline": m_cpu,
                      "config": {"workload": "BASELINE configs[4]: %d frames of Barrett hand (8 joints reduced to 4, proxy geometry) + box object, "
                                             "synthetic 1280x720 depth per frame, obs->mod + mod->obs + self / pairwise intersection in reduced "
                                             "dimensions, %d GN iterations per frame, frames sharded by index over %d GPU(s), one all-gather of "
@@ -523,7 +729,7 @@ def main():
                                    "prediction 320x240, 64^3 obs SDF, obs->mod + mod->obs, %d GN iterations per optimizePose call, "
                                    "normThreshold %.1f; one frame per GPU" % (iters, sc.opts.normThreshold),
                        "iterations_per_step": iters, "frames_per_gpu": 1, "parallelism": "independent frames, 1 per GPU"},
-            "repeats": repeats, "roofline": roofline, "cpu_baseline": cpu_baseline, "batched_grasps": grasps, "multi_model_tracking": multi,
+            "value_default_gate": value_default_gate, "repeats": repeats, "roofline": roofline, "cpu_baseline": cpu_baseline, "batched_grasps": grasps, "multi_model_tracking": multi,
         }
         print(json.dumps(line, default=float))
     if distributed:

@@ -619,7 +619,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         ws->partialLane = 1;
         if (useA) {
             {
-                ProfScope ps(DARTK_PROF_OTHER, stA);
+                ProfScope ps(DARTK_PROF_ASSOC_MULTI, stA);
                 rc = gn_assoc_multi_launch(d_vert, nPix, n, d_assocArgs, d_countA, stA, d_validIdx, d_nValid, assocStageBytes, false);
                 if (rc) return rc;
             }

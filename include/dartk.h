@@ -469,7 +469,8 @@ enum dartk_prof_class {
     DARTK_PROF_OBS_SDF = 0, DARTK_PROF_RAYCAST = 1 /* trace kernel */, DARTK_PROF_FUSED_OBS2MOD = 2, DARTK_PROF_NE_MOD2OBS = 3,
     DARTK_PROF_NE_SELF = 4, DARTK_PROF_SOLVE = 5, DARTK_PROF_RAYCAST_REPLAY = 6, DARTK_PROF_OTHER = 7, DARTK_PROF_REDUCE = 8,
     DARTK_PROF_NOOBS_TERMS = 9 /* self- and pairwise intersection term kernels */, DARTK_PROF_NOOBS_SOLVE = 10,
-    DARTK_PROF_NOOBS_PRIORS = 11 /* contact-prior term kernel */, DARTK_PROF_CLASSES = 12
+    DARTK_PROF_NOOBS_PRIORS = 11 /* contact-prior term kernel */, DARTK_PROF_ASSOC_MULTI = 12 /* multi-model association */,
+    DARTK_PROF_CLASSES = 13
 };
 /* Trilinear SDF lookups actually performed by the kernels since the last reset, by category: h_counts[8] = {other, association
  * scan, association gradient (normal test / fused Jacobian), obs->mod gradient, ray-cast march, mod->obs (value + gradient),

@@ -407,39 +407,64 @@ int orc_assoc_single(const float *vert, const float *norm, int width, int height
     return count;
 }
 
+/* one pixel of the multi-model association (obsToMod.cu:139-207): returns the model (-1 none), *gridOut, *errOut */
+static int assoc_multi_pixel(int index, const float *vert, int nModels, const orc_model *const *models, const float *T_mcs,
+                             const float *const *T_fms, const float *distanceThresholds, const float *planeOffsets,
+                             const float *planeNormals, int *gridOut, float *errOut) {
+    const float *xc = vert + 4 * index;
+    if (!(xc[3] > 0)) return -1;
+    float sdfError = 1e20f;
+    int aModel = -1, aGrid = -1;
+    for (int m = 0; m < nModels; ++m) {
+        float xm[4];
+        se3_apply4(T_mcs + 12 * m, xc, xm);
+        if (!(dot3(xm, planeNormals + 3 * m) >= planeOffsets[m])) continue;
+        const orc_model *mod = models[m];
+        for (int g = 0; g < mod->n_sdfs; ++g) {
+            const int f = mod->sdf_frame[g];
+            float xf[4], xg[3];
+            se3_apply4(T_fms[m] + 12 * f, xm, xf);
+            const orc_grid sdf = model_sdf(mod, g);
+            orc_grid_coords(&sdf, xf, xg);
+            if (!orc_grid_in_bounds_gradient_interp(&sdf, xg)) continue;
+            const float d = orc_grid_value_interp(&sdf, xg) * sdf.resolution;
+            if (d < sdfError) {
+                if (d * d < distanceThresholds[m] * distanceThresholds[m]) {
+                    sdfError = d; aGrid = g; aModel = m;
+                }
+            }
+        }
+    }
+    *gridOut = aGrid; *errOut = sdfError;
+    return aModel;
+}
+
 void orc_assoc_multi(const float *vert, const float *norm, int width, int height, int nModels,
                      const orc_model *const *models, const float *T_mcs, const float *const *T_fms,
                      const float *distanceThresholds, const float *planeOffsets, const float *planeNormals,
                      orc_da_point *const *pts, int32_t *counts, int32_t *dbgDA, float *dbgErr) {
     (void)norm;
+    const int nPix = width * height;
     for (int m = 0; m < nModels; ++m) counts[m] = 0;
-    for (int index = 0; index < width * height; ++index) {
+    const int oldcat = stat_enter(ORC_STAT_ASSOC);
+    int *amodel = NULL, *agrid = NULL;
+    float *aerr = NULL;
+    if (g_threads > 1) {        /* pixels are independent: decisions in parallel, the lists appended in pixel order afterwards */
+        amodel = (int *)malloc(sizeof(int) * (size_t)nPix);
+        agrid = (int *)malloc(sizeof(int) * (size_t)nPix);
+        aerr = (float *)malloc(sizeof(float) * (size_t)nPix);
+#pragma omp parallel for schedule(static, 1024) num_threads(g_threads)
+        for (int index = 0; index < nPix; ++index)
+            amodel[index] = assoc_multi_pixel(index, vert, nModels, models, T_mcs, T_fms, distanceThresholds, planeOffsets, planeNormals,
+                                              &agrid[index], &aerr[index]);
+    }
+    for (int index = 0; index < nPix; ++index) {
         if (dbgDA) dbgDA[index] = -1;
         if (dbgErr) dbgErr[index] = NAN;
-        const float *xc = vert + 4 * index;
-        if (!(xc[3] > 0)) continue;
-        float sdfError = 1e20f;
-        int aModel = -1, aGrid = -1;
-        for (int m = 0; m < nModels; ++m) {
-            float xm[4];
-            se3_apply4(T_mcs + 12 * m, xc, xm);
-            if (!(dot3(xm, planeNormals + 3 * m) >= planeOffsets[m])) continue;
-            const orc_model *mod = models[m];
-            for (int g = 0; g < mod->n_sdfs; ++g) {
-                const int f = mod->sdf_frame[g];
-                float xf[4], xg[3];
-                se3_apply4(T_fms[m] + 12 * f, xm, xf);
-                const orc_grid sdf = model_sdf(mod, g);
-                orc_grid_coords(&sdf, xf, xg);
-                if (!orc_grid_in_bounds_gradient_interp(&sdf, xg)) continue;
-                const float d = orc_grid_value_interp(&sdf, xg) * sdf.resolution;
-                if (d < sdfError) {
-                    if (d * d < distanceThresholds[m] * distanceThresholds[m]) {
-                        sdfError = d; aGrid = g; aModel = m;
-                    }
-                }
-            }
-        }
+        int aGrid = -1; float sdfError = 1e20f;
+        int aModel;
+        if (amodel) { aModel = amodel[index]; aGrid = agrid[index]; sdfError = aerr[index]; }
+        else aModel = assoc_multi_pixel(index, vert, nModels, models, T_mcs, T_fms, distanceThresholds, planeOffsets, planeNormals, &aGrid, &sdfError);
         if (aModel != -1) {
             if (dbgDA) dbgDA[index] = ((aModel << 16) | aGrid);
             if (dbgErr) dbgErr[index] = sdfError;
@@ -447,6 +472,8 @@ void orc_assoc_multi(const float *vert, const float *norm, int width, int height
             p->index = index; p->dataAssociation = aGrid; p->error = sdfError;
         }
     }
+    free(amodel); free(agrid); free(aerr);
+    stat_enter(oldcat);
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -12,6 +12,8 @@ with open(sys.argv[1]) as f:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("dartk::", "")
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
+import json
+rates = {}
 print("%-44s %8s %14s %14s %9s" % ("kernel", "launches", "L2 req/launch", "L2 miss/launch", "hit rate"))
 for k in sorted(tot, key=lambda k: -tot[k].get("TCC_REQ_sum", 0)):
     n = len(disp[k])
@@ -19,3 +21,6 @@ for k in sorted(tot, key=lambda k: -tot[k].get("TCC_REQ_sum", 0)):
     if hit + miss == 0:
         continue
     print("%-44s %8d %14.0f %14.0f %8.1f%%" % (k[:44], n, req / n, miss / n, 100.0 * hit / (hit + miss)))
+    rates[k] = {"launches": n, "hit_rate": round(hit / (hit + miss), 4), "requests_per_launch": round(req / n)}
+if len(sys.argv) > 2:       # JSON for bench.py (profiles/l2_hit_rate.json)
+    json.dump(rates, open(sys.argv[2], "w"), indent=1, sort_keys=True)

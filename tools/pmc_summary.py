@@ -10,16 +10,27 @@ import sys
 from collections import defaultdict
 
 
+LARGEST = False     # --largest: per kernel only the launches with at least half its largest grid (the batch pass: a process that
+                    # launches a kernel for 1 frame while it builds its inputs and for 64 frames in the timed loop)
+
+
 def per_kernel(path, counter):
     tot = defaultdict(float)
     disp = defaultdict(set)
+    rows = []
+    big = defaultdict(int)
     with open(path) as f:
         for r in csv.DictReader(f):
             if r["Counter_Name"] != counter:
                 continue
-            k = r["Kernel_Name"]
-            tot[k] += float(r["Counter_Value"])
-            disp[k].add(r["Dispatch_Id"])
+            rows.append(r)
+            big[r["Kernel_Name"]] = max(big[r["Kernel_Name"]], int(r["Grid_Size"]))
+    for r in rows:
+        k = r["Kernel_Name"]
+        if LARGEST and 2 * int(r["Grid_Size"]) < big[k]:
+            continue
+        tot[k] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
     return {k: (tot[k] / max(len(disp[k]), 1), len(disp[k])) for k in tot}
 
 
@@ -32,6 +43,10 @@ def short(name):
 
 
 def main():
+    global LARGEST
+    if "--largest" in sys.argv:
+        LARGEST = True
+        sys.argv.remove("--largest")
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     out, launches = {}, {}
