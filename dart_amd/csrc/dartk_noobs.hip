@@ -447,29 +447,12 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                     int dstSdf = -1;
                     float minV = 3.402823466e+38f;
                     const float *sph = sSph(pDst) + 4 * (slot < 0 ? 4 : slot);
-#ifdef DARTK_PRIOR_STATS
-                    {
-                        int myPass = 0;
-                        for (int ds = 0; ds < md.nSdfs; ++ds) {
-                            const bool ok = !sphere_reject(sph + kSphereStride * ds, pdm);
-                            myPass += ok;
-                            if (__builtin_amdgcn_ballot_w64(ok) != 0ull && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&g_lookupCount[1], 1ull);
-                        }
-                        atomicAdd(&g_lookupCount[2], (unsigned long long)myPass);
-                        int mx = myPass;
-                        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
-                        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) { atomicAdd(&g_lookupCount[3], (unsigned long long)mx); atomicAdd(&g_lookupCount[4], 1ull); }
-                    }
-#endif
                     for (int ds = 0; ds < md.nSdfs; ++ds) {
                         if (sphere_reject(sph + kSphereStride * ds, pdm)) continue;
                         const SdfDev &s = mdSdfs[ds];
                         const f3 df = se3_apply_w(dfm + 12 * mdFrame[ds], pdm.x, pdm.y, pdm.z, 1.0f);
                         const f3 g = grid_coords(s, df);
                         if (!in_bounds_interp(s, g) || !in_keep_box(s, slot, g)) continue;
-#ifdef DARTK_PRIOR_STATS
-                        atomicAdd(&g_lookupCount[5], 1ull);
-#endif
                         const float v = sdf_value<CNT_PRIOR>(md.grids, s, g);
                         if (v < minV) { minV = v; dstSdf = ds; }
                     }
