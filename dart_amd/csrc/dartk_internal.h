@@ -287,7 +287,7 @@ struct __attribute__((packed, aligned(4))) f2u { float a, b; };   // x-neighbour
 enum { CNT_OTHER = 0, CNT_ASSOC = 1, CNT_ASSOC_GRAD = 2, CNT_NE_O2M = 3, CNT_RAYCAST = 4, CNT_M2O = 5, CNT_INTER = 6, CNT_PRIOR = 7, CNT_N = 8 };
 #ifdef DARTK_COUNT_LOOKUPS
 static __device__ unsigned long long g_lookupCount[CNT_N];
-template <int CAT> __device__ __forceinline__ void count_lookup() { atomicAdd(&g_lookupCount[CAT], 1ull); }
+template <int CAT> __device__ __forceinline__ void count_lookup() { if constexpr (CAT >= 0) atomicAdd(&g_lookupCount[CAT], 1ull); }   // CAT < 0: not counted
 #else
 template <int CAT> __device__ __forceinline__ void count_lookup() {}
 #endif

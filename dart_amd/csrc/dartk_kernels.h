@@ -251,6 +251,37 @@ __device__ __forceinline__ Collision first_collision(const ModelView &dst, const
     return c;
 }
 
+// The same walk when the caller already knows, per lane, which destination SDFs are possible at all (`allowed`: potential matrix and
+// a tile-level sphere test folded in) and which some lane of the wave may want (`loop`, wave-uniform): only those are visited, in SDF
+// order -- every lane still meets its candidates in the reference's order and stops at its first penetrated one.
+__device__ __forceinline__ Collision first_collision_masked(const ModelView &dst, const float *T_fm_dst, f3 v_dm, const float *sph,
+                                                            unsigned long long allowed, unsigned long long loop) {
+    Collision c;
+    c.hit = false; c.dstGrid = -1; c.residual = 0.0f; c.vg.x = c.vg.y = c.vg.z = 0.0f;
+    unsigned long long cand = 0ull, any = 0ull;
+    for (unsigned long long todo = loop; todo != 0ull; todo &= todo - 1ull) {
+        const int g = (int)__builtin_ctzll(todo);
+        const bool ok = ((allowed >> g) & 1ull) && !sphere_reject(sph + kSphereStride * g, v_dm);
+        cand |= (unsigned long long)ok << g;
+        if (__builtin_amdgcn_ballot_w64(ok) != 0ull) any |= 1ull << g;
+    }
+    while (any != 0ull) {
+        const int g = (int)__builtin_ctzll(any);
+        any &= any - 1ull;
+        if ((cand >> g) & 1ull) {
+            const SdfDev &s = dst.sdfs[g];
+            const int f = dst.sdfFrame[g];
+            const f3 vd = se3_apply_w(T_fm_dst + 12 * f, v_dm.x, v_dm.y, v_dm.z, 1.0f);
+            const f3 vg = grid_coords(s, vd);
+            if (in_bounds_grad_interp(s, vg) && in_keep_box(s, 0, vg)) {       // r < 0 needs a negative corner
+                const float r = sdf_value<CNT_INTER>(dst.grids, s, vg) * s.res;
+                if (r < 0) { c.hit = true; c.dstGrid = g; c.residual = r; c.vg = vg; cand = 0ull; }
+            }
+        }
+    }
+    return c;
+}
+
 // Copy the pose-dependent transforms and the SDF header table into LDS (once per workgroup); used where the
 // frame / SDF index differs per lane.
 __device__ __forceinline__ void stage_model(const ModelView &m, float *sT_fm, float *sT_mf, SdfDev *sSdf) {

@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 namespace dartk {
@@ -34,8 +35,18 @@ __host__ __device__ constexpr bool term_weighted(int type) { return term_contact
 enum { NOOBS_USE_CONTACTS = 1, NOOBS_MOVE_CONTACTS = 2 };      // flags of a terms launch
 static constexpr int NOOBS_MAX_TERMS = DARTK_MAX_MODELS * DARTK_MAX_MODELS + 2;
 
+// Bounding spheres of one wave's 64 consecutive cloud points (intersection terms), built once at dartk_noobs_create: the clouds are
+// static in their SDFs' frames and arrive grouped by SDF and Z-ordered, so a 64-point tile is one compact patch of one link (or the
+// tail of one link and the head of the next: two segments). A sphere is given in the frame of its segment's SDF.
+struct TileMeta {
+    float cA[3], rA, cB[3], rB;     // segment A = lanes [0, split), segment B = lanes [split, 64)
+    int gridA, gridB, split;
+    int ok;                         // 0: more than two SDFs in the tile (or not grouped): no tile-level test
+};
+
 struct NoObsTerm {
     int type, src, dst;
+    const TileMeta *tiles;       // [ceil(nPoints / 64)] or null
     int nPoints, nBlocks;        // points (cloud sites / priors) and workgroups (= slabs) of this term per candidate
     int dims, S;                 // dimension / packed length of the term's system
     int slabOff;                 // offset (floats) of the term's slabs inside a candidate's slab area
@@ -150,6 +161,30 @@ noobs_load_poses_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ 
     fk_wave(m, 0, sT);
 }
 
+// Destination SDFs that a 64-point tile segment can possibly penetrate: its bounding sphere (centre c in the frame of source SDF
+// `grid`, radius R) against the sphere of every destination SDF's negative-value box (make_spheres slot 0, destination model frame).
+// Wave-uniform arithmetic, once per tile instead of once per lane. Conservative: a point p of the segment has |p - C| <= R (the
+// stored R carries a margin far above the rounding of the two transform paths), so |C - c_g| > R + r_g puts every point outside
+// sphere g, hence outside the box, hence the exact path would have found no negative value there: the decisions are unchanged.
+// T_ds: source model -> destination model (pairwise term) or null (self term, where pot = the potential-intersection row applies).
+__device__ __forceinline__ unsigned long long tile_candidates(const float *c, float R, int grid, const int *srcSdfFrame, const float *T_mf_src,
+                                                              const float *T_ds, const float *sphDst, int nDst, const int *pot, int nSrc) {
+    const f3 cm = se3_apply_w(T_mf_src + 12 * srcSdfFrame[grid], c[0], c[1], c[2], 1.0f);
+    f3 cd = cm;
+    if (T_ds) cd = se3_apply_w(T_ds, cm.x, cm.y, cm.z, 1.0f);
+    unsigned long long mask = 0ull;
+    for (int g = 0; g < nDst; ++g) {
+        if (pot && !pot[g + grid * nSrc]) continue;
+        const float *sp = sphDst + kSphereStride * g;
+        const float r2 = sp[3];
+        if (!(r2 >= 0.0f)) continue;                    // empty box: nothing to penetrate
+        const float dx = cd.x - sp[0], dy = cd.y - sp[1], dz = cd.z - sp[2];
+        const float reach = R + sqrtf(r2) + 1e-5f;
+        if (dx * dx + dy * dy + dz * dz <= reach * reach) mask |= 1ull << g;
+    }
+    return mask;
+}
+
 // -----------------------------------------------------------------------------------------------------
 // one term of one iteration, grid (workgroups of the term, candidate); one instantiation per term type so that the
 // register budget of the contact-prior path does not set the occupancy of the intersection paths.
@@ -256,9 +291,50 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     }
     __syncthreads();
 
+    // Intersection terms: which destination SDFs each of this workgroup's 64-point tiles can reach at all (tile_candidates), for
+    // ALL its tiles at once, one (tile, segment) per thread -- wave-uniform arithmetic costs a SIMD as much as per-lane arithmetic,
+    // so the tile test only pays when 64 tiles share one instruction stream. Most tiles of a hand's cloud are nowhere near the
+    // other model (or near a link they may collide with): their waves then skip the point transform and the per-SDF walk.
+    [[maybe_unused]] unsigned long long *sCull = nullptr;
+    [[maybe_unused]] int *sCullSplit = nullptr;
+    [[maybe_unused]] int tileIter = 0;
+    if constexpr (TYPE == TERM_SELF || TYPE == TERM_INTER) {
+        const ModelView &dm = (TYPE == TERM_SELF) ? src : dst;
+        if (T.tiles && dm.nSdfs <= 64) {
+            const int nT = (T.nPoints + NE_BLOCK - 1) / NE_BLOCK;
+            const int mine = ((int)blockIdx.x < nT) ? (nT - (int)blockIdx.x + T.nBlocks - 1) / T.nBlocks : 0;     // tiles of this workgroup
+            float *endF = sFullJ + ((P->anyReduced) ? NOOBS_ROWS * fullLd : 0);
+            sCull = reinterpret_cast<unsigned long long *>(lds + ((((int)(endF - lds)) + 1) & ~1));
+            sCullSplit = reinterpret_cast<int *>(sCull + 4 * mine);
+            const int nWaveTiles = (T.nPoints + 63) / 64;
+            const float *T_ds = (TYPE == TERM_INTER) ? sT_ds : nullptr;
+            const int *pot = (TYPE == TERM_SELF) ? potPtr : nullptr;
+            const float *sph = (TYPE == TERM_SELF) ? sSph(T.src) : sSph(T.dst);
+            for (int w = threadIdx.x; w < 4 * mine; w += blockDim.x) {
+                const int seg = w & 1, k = w >> 1;
+                const int wt = ((int)blockIdx.x + (k >> 1) * T.nBlocks) * (NE_BLOCK / 64) + (k & 1);
+                unsigned long long mask = ~0ull;
+                int split = -1;
+                if (wt < nWaveTiles) {
+                    const TileMeta tm = T.tiles[wt];
+                    if (tm.ok) {
+                        split = tm.split;
+                        if (seg == 0) mask = tile_candidates(tm.cA, tm.rA, tm.gridA, src.sdfFrame, sTf(T.src) + 12 * src.nFrames, T_ds, sph, dm.nSdfs, pot, src.nSdfs);
+                        else mask = (tm.split < 64) ? tile_candidates(tm.cB, tm.rB, tm.gridB, src.sdfFrame, sTf(T.src) + 12 * src.nFrames, T_ds, sph,
+                                                                       dm.nSdfs, pot, src.nSdfs) : 0ull;
+                    }
+                }
+                sCull[w] = mask;
+                if (seg == 0) sCullSplit[k] = split;
+            }
+            __syncthreads();
+        }
+    }
     NOOBS_STAMP(0);
-    TileAcc<NE_BLOCK, TPT> acc;
+    // TPT == 0: the outer product runs on the matrix cores (systems of at most 32 dimensions, MfmaAcc), else on 4x4 VALU tiles
+    std::conditional_t<TPT == 0, MfmaAcc<NE_BLOCK>, TileAcc<NE_BLOCK, (TPT > 0 ? TPT : 1)>> acc;
     acc.init(d);
+    if constexpr (TPT == 0) acc.dims = d;
     NOOBS_STAMP(1);
     constexpr bool WEIGHTED = term_weighted(TYPE);
     constexpr bool UPD = TYPE == TERM_PRIORS_UPD;
@@ -281,7 +357,9 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                 const float weight = row[14], E = row[15];
                 const int srcFrame = packed & 0xff, dstFrame = (packed >> 8) & 0xff, pSrc = (packed >> 16) & 0xf, pDst = (packed >> 20) & 0xf;
                 const bool upSrc = (packed >> 24) & 1, upDst = (packed >> 25) & 1;
-                for (int i = 0; i < ld; ++i) row[i] = 0.0f;
+                // the J^T J operand R = [r | E | w*L_0 .. w*L_{d-1} | 0 ..] is written in full below; L starts as zeros (the walks
+                // fill the dependent joints only)
+                for (int i = 2 + d; i < ld; ++i) row[i] = 0.0f;
                 float *L = row + lOff;
                 const ModelView &ms = P->model[pSrc];
                 const ModelView &md = P->model[pDst];
@@ -292,20 +370,24 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                     error_jacobian_walk<false, false>(L + P->off[pSrc], pm, 1.0f, ms.depMask[srcFrame], gs, P->dims[pSrc] - 6,
                                                       sJType(pSrc, ms.nSdfs), sJAxis(pSrc, ms.nSdfs, ms.nJoints), sTf(pSrc),
                                                       sTf(pSrc) + 12 * ms.nFrames);
+                int negLo = 0, negHi = 0;       // the destination model's columns enter with the opposite sign (:118-126)
                 if (upDst) {
                     float *rd = L + P->off[pDst];
                     error_jacobian_walk<false, false>(rd, pdm, 1.0f, md.depMask[dstFrame], gdm, P->dims[pDst] - 6,
                                                       sJType(pDst, md.nSdfs), sJAxis(pDst, md.nSdfs, md.nJoints), sTf(pDst),
                                                       sTf(pDst) + 12 * md.nFrames);
-                    const int nd = P->dims[pDst];
-                    for (int i = 0; i < nd; ++i) rd[i] = -rd[i];
+                    negLo = P->off[pDst]; negHi = negLo + P->dims[pDst];
                 }
                 L[d] = 1.0f;
                 // J^T e += (w*err) * J (:128); a prior that also solves for its contact point parks that factor with the
                 // contact point's share of the back substitution already taken out (see the evaluation below)
                 row[0] = (UPD && ((packed >> 26) & 1)) ? residual : weight * residual;
                 row[1] = E;
-                for (int i = 0; i < d; ++i) row[2 + i] = weight * L[i];      // (w*J) J^T   (:129)
+                for (int i = 0; i < d; ++i) {       // (w*J) J^T   (:129), the sign flip of the destination block in the same pass
+                    float v = L[i];
+                    if (i >= negLo && i < negHi) { v = -v; L[i] = v; }
+                    row[2 + i] = weight * v;
+                }
             } else {
                 for (int i = d + 3; i < ld; ++i) row[i] = 0.0f;
                 const int red = P->redType[T.src];
@@ -345,34 +427,58 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         float residual = 0.0f, weight = 0.0f, E = 0.0f;
         bool upSrc = true, upDst = false;
         bool folded = false;                   // the parked residual already is the row's J^T e factor (TERM_PRIORS_UPD)
+        // intersection terms: which destination SDFs this wave's 64 points can reach at all (tile_candidates). Most tiles of a
+        // hand's cloud are nowhere near the other model (or near a link they may collide with): they cost one scalar-rate sphere
+        // test per destination SDF instead of 64 lanes x (transform + per-SDF tests).
+        [[maybe_unused]] unsigned long long allowed = ~0ull, tileLoop = ~0ull;
+        [[maybe_unused]] bool tileOk = false;
+        if constexpr (TYPE == TERM_SELF || TYPE == TERM_INTER) {
+            if (sCull) {
+                const int k = 2 * tileIter + (int)(threadIdx.x >> 6);      // this wave's tile among the workgroup's
+                const int split = sCullSplit[k];
+                if (split >= 0) {
+                    tileOk = true;
+                    const unsigned long long mA = sCull[2 * k], mB = sCull[2 * k + 1];
+                    tileLoop = mA | mB;
+                    allowed = ((int)(threadIdx.x & 63) < split) ? mA : mB;
+                }
+            }
+            ++tileIter;
+        }
         if (index < T.nPoints) {
             if constexpr (TYPE == TERM_SELF) {
-                const float4 v = T.cloud[index];
-                const int srcGrid = (int)roundf(v.w);
-                srcFrame = src.sdfFrame[srcGrid];
-                pm = se3_apply_w(sTf(T.src) + 12 * src.nFrames + 12 * srcFrame, v.x, v.y, v.z, 1.0f);
-                const Collision col = first_collision(src, sTf(T.src), pm, potPtr, srcGrid, sSph(T.src));
-                if (col.hit) {
-                    const SdfDev &s = src.sdfs[col.dstGrid];
-                    const f3 gf = sdf_gradient<CNT_INTER>(src.grids, s, col.vg);
-                    gs = se3_rotate(sTf(T.src) + 12 * src.nFrames + 12 * src.sdfFrame[col.dstGrid], gf);
-                    residual = col.residual;
-                    active = true;
+                if (allowed != 0ull) {
+                    const float4 v = T.cloud[index];
+                    const int srcGrid = (int)roundf(v.w);
+                    srcFrame = src.sdfFrame[srcGrid];
+                    pm = se3_apply_w(sTf(T.src) + 12 * src.nFrames + 12 * srcFrame, v.x, v.y, v.z, 1.0f);
+                    const Collision col = tileOk ? first_collision_masked(src, sTf(T.src), pm, sSph(T.src), allowed, tileLoop)
+                                                 : first_collision(src, sTf(T.src), pm, potPtr, srcGrid, sSph(T.src));
+                    if (col.hit) {
+                        const SdfDev &s = src.sdfs[col.dstGrid];
+                        const f3 gf = sdf_gradient<CNT_INTER>(src.grids, s, col.vg);
+                        gs = se3_rotate(sTf(T.src) + 12 * src.nFrames + 12 * src.sdfFrame[col.dstGrid], gf);
+                        residual = col.residual;
+                        active = true;
+                    }
                 }
             } else if constexpr (TYPE == TERM_INTER) {
-                const float4 v = T.cloud[index];
-                const int srcGrid = (int)roundf(v.w);
-                srcFrame = src.sdfFrame[srcGrid];
-                pm = se3_apply_w(sTf(T.src) + 12 * src.nFrames + 12 * srcFrame, v.x, v.y, v.z, 1.0f);
-                const f3 vdm = se3_apply_w(sT_ds, pm.x, pm.y, pm.z, 1.0f);
-                const Collision col = first_collision(dst, sTf(T.dst), vdm, nullptr, 0, sSph(T.dst));
-                if (col.hit) {
-                    const SdfDev &s = dst.sdfs[col.dstGrid];
-                    const f3 gf = sdf_gradient<CNT_INTER>(dst.grids, s, col.vg);
-                    const f3 gd = se3_rotate(sTf(T.dst) + 12 * dst.nFrames + 12 * dst.sdfFrame[col.dstGrid], gf);
-                    gs = se3_rotate(sT_ds + 12, gd);
-                    residual = col.residual;
-                    active = true;
+                if (allowed != 0ull) {
+                    const float4 v = T.cloud[index];
+                    const int srcGrid = (int)roundf(v.w);
+                    srcFrame = src.sdfFrame[srcGrid];
+                    pm = se3_apply_w(sTf(T.src) + 12 * src.nFrames + 12 * srcFrame, v.x, v.y, v.z, 1.0f);
+                    const f3 vdm = se3_apply_w(sT_ds, pm.x, pm.y, pm.z, 1.0f);
+                    const Collision col = tileOk ? first_collision_masked(dst, sTf(T.dst), vdm, sSph(T.dst), allowed, tileLoop)
+                                                 : first_collision(dst, sTf(T.dst), vdm, nullptr, 0, sSph(T.dst));
+                    if (col.hit) {
+                        const SdfDev &s = dst.sdfs[col.dstGrid];
+                        const f3 gf = sdf_gradient<CNT_INTER>(dst.grids, s, col.vg);
+                        const f3 gd = se3_rotate(sTf(T.dst) + 12 * dst.nFrames + 12 * dst.sdfFrame[col.dstGrid], gf);
+                        gs = se3_rotate(sT_ds + 12, gd);
+                        residual = col.residual;
+                        active = true;
+                    }
                 }
             } else if constexpr (TYPE == TERM_POINTS) {
                 // Point3D3DPrior / Point2D3DPrior::computeContribution (point_3d_3d_prior.cpp:6-69, point_2d_3d_prior.cpp:6-83):
@@ -773,6 +879,7 @@ struct NoObs {
     dartk_contact_prior *d_priors;
     dartk_point_prior *d_pointPriors;
     float *d_redTables;        // reductions: A | b | min | max per model, then the parameter maps
+    TileMeta *d_tileMeta[DARTK_MAX_MODELS];    // per model: bounding spheres of its collision cloud's 64-point tiles (or null)
     int nPriors;
     int maxBatch;
     int ldsModels, slabFloats;     // LDS floats of the staged model tables; slab floats per candidate of the fixed terms
@@ -788,6 +895,47 @@ struct NoObs {
 };
 
 DARTK_COUNTER_ACCESS(noobs)
+
+// TileMeta of a collision cloud (host copy [n][4], xyz in the owning SDF's frame, w = SDF number): per 64 consecutive points the
+// bounding sphere(s) of at most two runs of one SDF each; radii rounded up with a margin (1e-5 relative + 1e-6 m) far above the fp32
+// rounding of the device's transforms of the centre and of the points.
+static void build_tile_meta(const float *cloud, int n, int nSdfs, std::vector<TileMeta> &out) {
+    const int nTiles = (n + 63) / 64;
+    out.assign((size_t)nTiles, TileMeta{});
+    for (int tIdx = 0; tIdx < nTiles; ++tIdx) {
+        TileMeta &tm = out[(size_t)tIdx];
+        const int i0 = tIdx * 64, i1 = (i0 + 64 < n) ? i0 + 64 : n;
+        tm.ok = 1; tm.split = 64; tm.gridA = tm.gridB = 0;
+        int runs = 0, runStart[3] = {0, 0, 0}, runGrid[3] = {0, 0, 0};
+        for (int i = i0; i < i1; ++i) {
+            const int g = (int)roundf(cloud[4 * i + 3]);
+            if (g < 0 || g >= nSdfs) { tm.ok = 0; break; }
+            if (runs == 0 || g != runGrid[runs - 1]) {
+                if (runs == 2) { tm.ok = 0; break; }
+                runStart[runs] = i - i0; runGrid[runs] = g; ++runs;
+            }
+        }
+        if (!tm.ok || runs == 0) { tm.ok = 0; continue; }
+        auto sphere = [&](int a, int b, float *c, float &r) {       // points [i0 + a, i0 + b)
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (int i = i0 + a; i < i0 + b; ++i)
+                for (int k = 0; k < 3; ++k) { const double v = cloud[4 * i + k]; if (v < lo[k]) lo[k] = v; if (v > hi[k]) hi[k] = v; }
+            for (int k = 0; k < 3; ++k) c[k] = (float)(0.5 * (lo[k] + hi[k]));
+            double r2 = 0.0;
+            for (int i = i0 + a; i < i0 + b; ++i) {
+                double d2 = 0.0;
+                for (int k = 0; k < 3; ++k) { const double dlt = (double)cloud[4 * i + k] - (double)c[k]; d2 += dlt * dlt; }
+                if (d2 > r2) r2 = d2;
+            }
+            r = (float)(sqrt(r2) * (1.0 + 1e-5) + 1e-6);
+            if (!(r == r) || !(c[0] == c[0]) || !(c[1] == c[1]) || !(c[2] == c[2])) tm.ok = 0;       // NaN in the cloud: no tile test
+        };
+        const int end = i1 - i0;
+        tm.gridA = runGrid[0];
+        if (runs == 1) { sphere(0, end, tm.cA, tm.rA); tm.split = 64; tm.gridB = runGrid[0]; tm.rB = 0.0f; }
+        else { tm.split = runStart[1]; tm.gridB = runGrid[1]; sphere(0, tm.split, tm.cA, tm.rA); sphere(tm.split, end, tm.cB, tm.rB); }
+    }
+}
 
 }  // namespace dartk
 
@@ -816,6 +964,8 @@ static int noobs_launch_term(NoObs *t, int term, int batch, hipStream_t st) {
 template <int TYPE>
 static int noobs_launch_term_ppt(NoObs *t, int term, int batch, hipStream_t st) {
     const int tiles = tile_count(t->h.term[term].dims);     // 4x4 tiles of the packed system per workgroup
+    const bool noMfma = getenv("DARTK_NOOBS_NO_MFMA") != nullptr;       // diagnostic / test: the VALU tiles for every size
+    if (t->h.term[term].dims <= 32 && !noMfma) return noobs_launch_term<0, TYPE>(t, term, batch, st);
     if (tiles <= NE_BLOCK) return noobs_launch_term<1, TYPE>(t, term, batch, st);
     if (tiles <= 2 * NE_BLOCK) return noobs_launch_term<2, TYPE>(t, term, batch, st);
     set_error("term %d: system dimension %d needs more than %d accumulator tiles", term, t->h.term[term].dims, 2 * NE_BLOCK);
@@ -858,6 +1008,8 @@ int dartk_noobs_destroy(dartk_noobs_t h) {
     if (t->d_priors) (void)hipFree(t->d_priors);
     if (t->d_pointPriors) (void)hipFree(t->d_pointPriors);
     if (t->d_redTables) (void)hipFree(t->d_redTables);
+    for (int m = 0; m < DARTK_MAX_MODELS; ++m)
+        if (t->d_tileMeta[m]) (void)hipFree(t->d_tileMeta[m]);
     if (t->contactPts) (void)hipFree(t->contactPts);
     for (int m = 0; m < DARTK_MAX_MODELS; ++m)
         if (t->d_damping[m]) (void)hipFree(t->d_damping[m]);
@@ -963,11 +1115,29 @@ int dartk_noobs_create_reduced(int nModels, const dartk_model_t *models, const d
         T.nBlocks = noobs_blocks_per_term(tiles, maxBatch);
         T.slabOff = slabOff; slabOff += T.nBlocks * T.S;
         T.cloud = reinterpret_cast<const float4 *>(cloud); T.pot = pot;
+        // tile-level sphere tests pay for the self term, where they also fold the potential-intersection row of the tile's link
+        // (measured per launch of 4096 candidates: 416 -> 296 us); the pairwise terms got slower with them (hand -> one-SDF object:
+        // the per-lane test is a single sphere already, 433 -> 494 us; object -> hand 293 -> 311 us) and run without
+        T.tiles = (type == TERM_SELF) ? t->d_tileMeta[src] : nullptr;
         if (T.S > SMax) SMax = T.S;
         const int ld = noobs_row_len(type, dims);
+        const size_t cullFloats = (type == TERM_SELF || type == TERM_INTER) ? 2 + 10 * (size_t)((tiles + T.nBlocks - 1) / T.nBlocks) : 0;   // masks + splits
         t->ldsTerm[nTerms - 1] = sizeof(float) * ((size_t)ldsModels + (size_t)NOOBS_ROWS * ld + 8 + (type == TERM_SELF ? t->potLdsInts : 0) +
-                                                  (P.anyReduced && !term_weighted(type) ? (size_t)NOOBS_ROWS * (P.maxFullDims | 1) : 0));
+                                                  (P.anyReduced && !term_weighted(type) ? (size_t)NOOBS_ROWS * (P.maxFullDims | 1) : 0) + cullFloats);
     };
+    for (int m = 0; m < nModels; ++m) {      // tile spheres of every cloud that is the source of a self-intersection term
+        const bool used = h_lambdaIntersection[m + m * nModels] > 0 && P.dims[m] > 6;
+        if (!used || nCloudPoints[m] <= 0 || !d_clouds[m] || getenv("DARTK_NOOBS_NO_TILE_CULL")) continue;
+        std::vector<float> hc((size_t)4 * nCloudPoints[m]);
+        std::vector<TileMeta> meta;
+        hipError_t ec = hipMemcpy(hc.data(), d_clouds[m], sizeof(float) * hc.size(), hipMemcpyDeviceToHost);
+        if (ec == hipSuccess) {
+            build_tile_meta(hc.data(), nCloudPoints[m], P.model[m].nSdfs, meta);
+            ec = hipMalloc((void **)&t->d_tileMeta[m], sizeof(TileMeta) * meta.size());
+            if (ec == hipSuccess) ec = hipMemcpy(t->d_tileMeta[m], meta.data(), sizeof(TileMeta) * meta.size(), hipMemcpyHostToDevice);
+        }
+        if (ec != hipSuccess) { dartk_noobs_destroy(reinterpret_cast<dartk_noobs_t>(t)); set_error("dartk_noobs_create: %s", hipGetErrorString(ec)); return DARTK_ERR_HIP; }
+    }
     for (int m = 0; m < nModels; ++m) {
         if (h_lambdaIntersection[m + m * nModels] > 0 && nCloudPoints[m] > 0 && P.dims[m] > 6) {
             if (!d_clouds[m] || !d_potentials[m]) { delete t; set_error("model %d: self-intersection needs a cloud and a potential matrix", m); return DARTK_ERR_INVALID; }
@@ -1053,7 +1223,7 @@ static int noobs_set_points_term(NoObs *t, int n) {
         const int tiles = (T.nPoints + NE_BLOCK - 1) / NE_BLOCK;
         T.nBlocks = noobs_blocks_per_term(tiles, t->maxBatch);
         T.slabOff = slabOff; slabOff += T.nBlocks * T.S;
-        T.cloud = nullptr; T.pot = nullptr;
+        T.cloud = nullptr; T.pot = nullptr; T.tiles = nullptr;
         t->ldsTerm[P.nTerms] = sizeof(float) * ((size_t)t->ldsModels + (size_t)NOOBS_ROWS * noobs_row_len(TERM_POINTS, P.D) + 8);
         DARTK_REQUIRE(t->ldsTerm[P.nTerms] <= 160 * 1024, "LDS requirement exceeds 160 KiB");
         if (T.S > t->SMax) t->SMax = T.S;

@@ -226,6 +226,90 @@ struct TileAcc {
     }
 };
 
+// The same outer product on the matrix cores, for systems of at most 32 dimensions (the ContactGrasp block: hand 26 + object 6; every
+// intersection term of the hands here). rocprof on the batched term kernels showed the contraction -- not the SDF gathers -- to be
+// the largest single part of the contact-prior kernel (37 % of its time on the VALU, profiles/r03_*): north_star's condition for
+// moving it to MFMA. v_mfma_f32_32x32x2_f32 takes A[i][k] = L_i of row k and B[k][c] = R_c of row k, two rows per instruction, and
+// is an exact fp32 fma chain over k (MI355X_MICROARCH.md, "exact f32 = fmaf chain, bitwise"): with the rows fed in their order every
+// entry M[i][c], i < 32, c < 32, is the SAME chain TileAcc forms, bit for bit. One wave issues one instruction per two rows instead
+// of ~36 (reads + FMAs of its 4x4 tiles). What a 32 x 32 block cannot hold -- J^T J columns 30, 31 (c = 32, 33) and, for d = 32, the e
+// slot (i = 32) -- are at most four chains, kept by four lanes of the workgroup's second wave. BLOCK must be 128.
+template <int BLOCK>
+struct MfmaAcc {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 c;
+    float extra;            // leftover chain of this thread (second wave, lanes 0..3)
+    int ei, ec;             // its operands: L index, R index; ei < 0: none
+
+    __device__ __forceinline__ void init(int d, int tid = (int)threadIdx.x) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[e] = 0.0f;
+        extra = 0.0f; ei = -1; ec = 0;
+        const int q = tid - 64;
+        if (q >= 0 && q < 4) {
+            // wanted entries outside the block: (i, j) with j in {30, 31}, j <= i < d  ->  c = j + 2;   e (i = d, c = 1) when d == 32
+            int k = 0;
+            for (int j = 30; j < 32 && j < d; ++j)
+                for (int i = j; i < d && i < 32; ++i) { if (k == q) { ei = i; ec = j + 2; } ++k; }
+            if (d == 32) { if (k == q) { ei = 32; ec = 1; } ++k; }
+        }
+    }
+
+    // rows: LDS, n rows of stride ld; L_i = rows[lOff + i] (i <= d), R_c = rows[c]
+    template <bool WEIGHTED>
+    __device__ __forceinline__ void accumulate(const float *rows, int ld, int n, int lOff) {
+        const int tid = (int)threadIdx.x;
+        if (tid < 64) {
+            const int half = tid >> 5, col = tid & 31;
+            const int dTop = dims;
+            const float *pa = rows + half * ld + lOff + col, *pb = rows + half * ld + col;
+            for (int p = 0; p < n; p += 2, pa += 2 * ld, pb += 2 * ld) {
+                float a = 0.0f, b = 0.0f;
+                if (p + half < n) { a = (col <= dTop) ? *pa : 0.0f; b = *pb; }
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+            }
+        } else if (ei >= 0) {
+            const float *pl = rows + lOff + ei, *pr = rows + ec;
+            for (int p = 0; p < n; ++p, pl += ld, pr += ld) extra = __builtin_fmaf(*pl, *pr, extra);
+        }
+    }
+
+    __device__ __forceinline__ void add_e(int d, double v) {
+        const int tid = (int)threadIdx.x;
+        if (d == 32) {
+            if (tid >= 64 && ei == 32) extra = (float)((double)extra + v);
+            return;
+        }
+        if (tid < 64 && (tid & 31) == 1) {          // M[d][1]: column 1, row d = (reg & 3) + 8 (reg >> 2) + 4 half
+            const int half = tid >> 5;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if ((e & 3) + 8 * (e >> 2) + 4 * half == d) c[e] = (float)((double)c[e] + v);
+        }
+    }
+
+    __device__ __forceinline__ void store(float *slab, int d) const {
+        const int S = sys_size(d);
+        const int tid = (int)threadIdx.x;
+        if (tid < 64) {
+            const int half = tid >> 5, cc = tid & 31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = (e & 3) + 8 * (e >> 2) + 4 * half;
+                int o = -1;
+                if (i < d && cc == 0) o = i;
+                else if (i == d && cc == 1) o = S - 1;
+                else if (i < d && cc >= 2 && cc - 2 <= i) o = d + ((i * (i + 1)) >> 1) + (cc - 2);
+                if (o >= 0) slab[o] = c[e];
+            }
+        } else if (ei >= 0) {
+            slab[ei == d ? S - 1 : d + ((ei * (ei + 1)) >> 1) + (ec - 2)] = extra;
+        }
+    }
+
+    int dims;       // set by the kernel before the first accumulate (rows beyond L_d hold another row's data)
+};
+
 // Deterministic compaction slot for this thread inside its workgroup: returns the row index (or -1 when
 // inactive) and the workgroup's active count. `waveCnt` is an LDS array of BLOCK/64 ints.
 template <int BLOCK>

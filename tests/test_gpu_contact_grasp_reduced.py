@@ -137,3 +137,22 @@ def test_reduced_refinement_matches_oracle(gpu, kind):
     for c in range(len(T)):
         sT, sj, se_, _, _ = tr.optimizePosesBatch(T[c:c + 1], J[c:c + 1])
         assert np.abs(sT[0] - bT[c]).max() < 1e-4 and np.abs(sj[0] - bj[c]).max() < 1e-4
+
+
+@pytest.mark.parametrize("switch", ["DARTK_NOOBS_NO_MFMA", "DARTK_NOOBS_NO_TILE_CULL"])
+def test_contraction_and_culling_variants_are_bit_identical(gpu, switch, monkeypatch):
+    """Systems of <= 32 dimensions are contracted with v_mfma_f32_32x32x2_f32 (an fp32 fma chain in row order, the same chain the
+    VALU register tiles run) and the self-intersection term skips (tile, SDF) pairs whose bounding spheres are apart: both are
+    pure accelerations, so the first system, the per-iteration records and the end poses must not change by a single bit when the
+    diagnostic switches turn them off. (The culling switch is read when a model is added: a second tracker is built under it.)"""
+    def run():
+        sc, tr, priors, T, J = barrett_scene("linear")
+        tr.getOptions().numIterations = 6
+        return tr.optimizePosesBatch(T, J, debug=True)
+    a = run()
+    monkeypatch.setenv(switch, "1")
+    b = run()
+    for x, y in zip(a, b):
+        x, y = np.asarray(x), np.asarray(y)
+        assert x.shape == y.shape and x.tobytes() == y.tobytes()
+    assert np.count_nonzero(a[4]) > 60
