@@ -480,6 +480,55 @@ __device__ __forceinline__ void error_jacobian_walk(float *J, f3 pm, float pw, u
     }
 }
 
+// The same entries again with the row shared by the 4 neighbouring lanes q = 0..3 of one wave: entry k of J (pose columns and
+// joints alike) is written by the lane with ((k + phase) & 3) == q and by no other, so a row costs a quarter of the walk's
+// latency when few rows are pending. Entry for entry the arithmetic of error_jacobian; ZERO clears this lane's joints first.
+template <bool ARTIC_ONLY, bool ZERO>
+__device__ __forceinline__ void error_jacobian_walk4(float *J, f3 pm, float pw, unsigned long long depMask, f3 grad, int nJoints,
+                                                     const int *sJointType, const float *sJointAxis, const float *T_fm,
+                                                     const float *T_mf, int q, int phase) {
+    int aOff = 0;
+    if (!ARTIC_ONLY) {
+        for (int k = (q - phase) & 3; k < 6; k += 4) {
+            float v;
+            switch (k) {
+                case 0: v = grad.x * -1.0f + grad.y * 0.0f + grad.z * 0.0f; break;
+                case 1: v = grad.x * 0.0f + grad.y * -1.0f + grad.z * 0.0f; break;
+                case 2: v = grad.x * 0.0f + grad.y * 0.0f + grad.z * -1.0f; break;
+                case 3: v = grad.x * 0.0f + grad.y * pm.z + grad.z * -pm.y; break;
+                case 4: v = grad.x * -pm.z + grad.y * 0.0f + grad.z * pm.x; break;
+                default: v = grad.x * pm.y + grad.y * -pm.x + grad.z * 0.0f; break;
+            }
+            J[k] = v;
+        }
+        aOff = 6;
+    }
+    float *Ja = J + aOff;
+    const int first = (q - phase - aOff) & 3;      // this lane's joints: first, first + 4, ..
+    if (ZERO)
+        for (int i = first; i < nJoints; i += 4) Ja[i] = 0.0f;
+    unsigned long long todo = nJoints < 64 ? depMask & ((1ull << nJoints) - 1ull) : depMask;
+    todo &= 0x1111111111111111ull << first;
+    while (todo) {
+        const int i = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int jf = i + 1;
+        const float *Tm = T_mf + 12 * jf;
+        f3 ax; ax.x = sJointAxis[3 * i]; ax.y = sJointAxis[3 * i + 1]; ax.z = sJointAxis[3 * i + 2];
+        float v;
+        if (sJointType[i] == 0) {
+            const f3 rel = se3_apply_w(T_fm + 12 * jf, pm.x, pm.y, pm.z, pw);
+            const f3 dxa = cross(ax, rel);
+            const f3 dx = se3_rotate(Tm, dxa);
+            v = dot(grad, dx);
+        } else {
+            const f3 axm = se3_rotate(Tm, ax);
+            v = dot(grad, axm);
+        }
+        Ja[i] = v;
+    }
+}
+
 #endif  // __HIPCC__
 
 }  // namespace dartk

@@ -344,8 +344,12 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     auto flush = [&](int n) {
         __syncthreads();
         NOOBS_STAMP(3);
-        if ((int)threadIdx.x < n) {
-            float *row = rows + threadIdx.x * ld;
+        // 4 neighbouring lanes share a row: every entry of the row is written by exactly one of them (error_jacobian_walk4), the
+        // parked state is read by all four before any of them writes (same wave: LDS accesses complete in program order)
+        static_assert(4 * NOOBS_ROWS <= NE_BLOCK, "4 lanes per pending row");
+        const int rowIdx = threadIdx.x >> 2, q = threadIdx.x & 3;
+        if (rowIdx < n) {
+            float *row = rows + rowIdx * ld;
             f3 pm, gs;
             pm.x = row[0]; pm.y = row[1]; pm.z = row[2]; gs.x = row[3]; gs.y = row[4]; gs.z = row[5];
             const float residual = row[6];
@@ -355,56 +359,64 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                 f3 pdm, gdm;
                 pdm.x = row[8]; pdm.y = row[9]; pdm.z = row[10]; gdm.x = row[11]; gdm.y = row[12]; gdm.z = row[13];
                 const float weight = row[14], E = row[15];
+                __builtin_amdgcn_wave_barrier();
                 const int srcFrame = packed & 0xff, dstFrame = (packed >> 8) & 0xff, pSrc = (packed >> 16) & 0xf, pDst = (packed >> 20) & 0xf;
                 const bool upSrc = (packed >> 24) & 1, upDst = (packed >> 25) & 1;
                 // the J^T J operand R = [r | E | w*L_0 .. w*L_{d-1} | 0 ..] is written in full below; L starts as zeros (the walks
-                // fill the dependent joints only)
-                for (int i = 2 + d; i < ld; ++i) row[i] = 0.0f;
+                // fill the dependent joints only). Lane q owns the entries L[i] with (i & 3) == q, from zeroing to scaling.
                 float *L = row + lOff;
+                for (int i = 2 + d + q; i < lOff; i += 4) row[i] = 0.0f;
+                for (int i = q; i < ld - lOff; i += 4) L[i] = 0.0f;       // (lOff >= 2 + d, tile_l_off)
                 const ModelView &ms = P->model[pSrc];
                 const ModelView &md = P->model[pDst];
                 // The priors index the model's Jacobian by the pose's REDUCED dimensions (contact_prior.cpp:31-32,110-126:
                 // subJ(i) = dot(grad, J3D[i]) for i < getReducedDimensions(), J3D being the FULL Jacobian): for a reduced pose
                 // that is the first 6 + redArt columns of the full Jacobian, kept as the reference computes it
                 if (upSrc)
-                    error_jacobian_walk<false, false>(L + P->off[pSrc], pm, 1.0f, ms.depMask[srcFrame], gs, P->dims[pSrc] - 6,
-                                                      sJType(pSrc, ms.nSdfs), sJAxis(pSrc, ms.nSdfs, ms.nJoints), sTf(pSrc),
-                                                      sTf(pSrc) + 12 * ms.nFrames);
+                    error_jacobian_walk4<false, false>(L + P->off[pSrc], pm, 1.0f, ms.depMask[srcFrame], gs, P->dims[pSrc] - 6,
+                                                       sJType(pSrc, ms.nSdfs), sJAxis(pSrc, ms.nSdfs, ms.nJoints), sTf(pSrc),
+                                                       sTf(pSrc) + 12 * ms.nFrames, q, P->off[pSrc]);
                 int negLo = 0, negHi = 0;       // the destination model's columns enter with the opposite sign (:118-126)
                 if (upDst) {
                     float *rd = L + P->off[pDst];
-                    error_jacobian_walk<false, false>(rd, pdm, 1.0f, md.depMask[dstFrame], gdm, P->dims[pDst] - 6,
-                                                      sJType(pDst, md.nSdfs), sJAxis(pDst, md.nSdfs, md.nJoints), sTf(pDst),
-                                                      sTf(pDst) + 12 * md.nFrames);
+                    error_jacobian_walk4<false, false>(rd, pdm, 1.0f, md.depMask[dstFrame], gdm, P->dims[pDst] - 6,
+                                                       sJType(pDst, md.nSdfs), sJAxis(pDst, md.nSdfs, md.nJoints), sTf(pDst),
+                                                       sTf(pDst) + 12 * md.nFrames, q, P->off[pDst]);
                     negLo = P->off[pDst]; negHi = negLo + P->dims[pDst];
                 }
-                L[d] = 1.0f;
+                if ((d & 3) == q) L[d] = 1.0f;
                 // J^T e += (w*err) * J (:128); a prior that also solves for its contact point parks that factor with the
                 // contact point's share of the back substitution already taken out (see the evaluation below)
-                row[0] = (UPD && ((packed >> 26) & 1)) ? residual : weight * residual;
-                row[1] = E;
-                for (int i = 0; i < d; ++i) {       // (w*J) J^T   (:129), the sign flip of the destination block in the same pass
+                if (q == 0) {
+                    row[0] = (UPD && ((packed >> 26) & 1)) ? residual : weight * residual;
+                    row[1] = E;
+                }
+                for (int i = q; i < d; i += 4) {       // (w*J) J^T   (:129), the sign flip of the destination block in the same pass
                     float v = L[i];
                     if (i >= negLo && i < negHi) { v = -v; L[i] = v; }
                     row[2 + i] = weight * v;
                 }
             } else {
-                for (int i = d + 3; i < ld; ++i) row[i] = 0.0f;
+                __builtin_amdgcn_wave_barrier();
+                for (int i = d + 3 + q; i < ld; i += 4) row[i] = 0.0f;
                 const int red = P->redType[T.src];
                 if (red == 0) {
-                    error_jacobian_walk<TYPE == TERM_SELF>(row + 2, pm, 1.0f, src.depMask[packed], gs, src.nJoints, sJType(T.src, src.nSdfs),
-                                                           sJAxis(T.src, src.nSdfs, src.nJoints), sTf(T.src), sTf(T.src) + 12 * src.nFrames);
-                } else {        // normEqns*Reduced / *ParamMap (intersection.cu:147-300, 445-597): full Jacobian, then its reduction
-                    float *Jf = sFullJ + threadIdx.x * fullLd;
+                    error_jacobian_walk4<TYPE == TERM_SELF, true>(row + 2, pm, 1.0f, src.depMask[packed], gs, src.nJoints, sJType(T.src, src.nSdfs),
+                                                                  sJAxis(T.src, src.nSdfs, src.nJoints), sTf(T.src), sTf(T.src) + 12 * src.nFrames,
+                                                                  q, 0);
+                } else if (q == 0) {        // normEqns*Reduced / *ParamMap (intersection.cu:147-300, 445-597): full Jacobian, then its reduction
+                    float *Jf = sFullJ + rowIdx * fullLd;
                     error_jacobian_walk<TYPE == TERM_SELF>(Jf, pm, 1.0f, src.depMask[packed], gs, src.nJoints, sJType(T.src, src.nSdfs),
                                                            sJAxis(T.src, src.nSdfs, src.nJoints), sTf(T.src), sTf(T.src) + 12 * src.nFrames);
                     const int fullDims = 6 + src.nJoints, redDims = P->dims[T.src];
                     if (red == 1) reduce_jacobian<1>(row + 2, Jf, TYPE == TERM_SELF ? 0 : 6, fullDims, redDims, P->redA[T.src], nullptr);
                     else reduce_jacobian<2>(row + 2, Jf, TYPE == TERM_SELF ? 0 : 6, fullDims, redDims, nullptr, P->redMap[T.src]);
                 }
-                row[0] = residual;
-                row[1] = (float)(0.5 * (double)residual * (double)residual);
-                row[d + 2] = 1.0f;
+                if (q == 0) {
+                    row[0] = residual;
+                    row[1] = (float)(0.5 * (double)residual * (double)residual);
+                    row[d + 2] = 1.0f;
+                }
             }
         }
         __syncthreads();
