@@ -190,6 +190,15 @@ __device__ __forceinline__ unsigned long long tile_candidates(const float *c, fl
 // register budget of the contact-prior path does not set the occupancy of the intersection paths.
 // LDS: per model [T_fm | T_mf] (24*nFrames) | per model spheres (20*nSdfs) | rows | wave counters | potential-intersection matrix (self term)
 // -----------------------------------------------------------------------------------------------------
+#ifndef NOOBS_ACC_LDS
+#define NOOBS_ACC_LDS 1
+#endif
+#ifndef NOOBS_DEFER_GRAD_SELF
+#define NOOBS_DEFER_GRAD_SELF 1
+#endif
+#ifndef NOOBS_DEFER_GRAD_INTER
+#define NOOBS_DEFER_GRAD_INTER 1
+#endif
 #ifndef NOOBS_WAVES_PRIORS
 #define NOOBS_WAVES_PRIORS 4
 #endif
@@ -248,11 +257,16 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         const int n = 12 * mv.nFrames;
         for (int i = threadIdx.x; i < n; i += blockDim.x) { p[i] = mv.T_fm[i]; p[n + i] = mv.T_mf[i]; }
     }
-#define sTf(mi) (lds + sOff[mi])
-#define sSph(mi) (lds + sSphOff[mi])
-#define sSdf(mi) (reinterpret_cast<const SdfDev *>(lds + sSdfOff[mi]))
-#define sFrm(mi, nSdfs_) (reinterpret_cast<const int *>(lds + sSdfOff[mi]) + kSdfWords * (nSdfs_))
-#define sPoseT(mi, nSdfs_) (lds + sSdfOff[mi] + (kSdfWords + 1) * (nSdfs_))      /* T_mc at +0, T_cm at +12 */
+    // The offsets come out of LDS, i.e. in vector registers even where every lane reads the same one: the intersection terms index
+    // them with the term's (wave-uniform) models, so they are moved to scalar registers there -- a dozen vector registers that the
+    // test loops otherwise spill. The prior terms index them with each lane's own prior's models.
+    constexpr bool UNI = (TYPE == TERM_SELF || TYPE == TERM_INTER);
+#define uniOff(x) (UNI ? __builtin_amdgcn_readfirstlane(x) : (x))
+#define sTf(mi) (lds + uniOff(sOff[mi]))
+#define sSph(mi) (lds + uniOff(sSphOff[mi]))
+#define sSdf(mi) (reinterpret_cast<const SdfDev *>(lds + uniOff(sSdfOff[mi])))
+#define sFrm(mi, nSdfs_) (reinterpret_cast<const int *>(lds + uniOff(sSdfOff[mi])) + kSdfWords * (nSdfs_))
+#define sPoseT(mi, nSdfs_) (lds + uniOff(sSdfOff[mi]) + (kSdfWords + 1) * (nSdfs_))      /* T_mc at +0, T_cm at +12 */
 #define sJType(mi, nSdfs_) (reinterpret_cast<const int *>(sPoseT(mi, nSdfs_) + 24))
 #define sJAxis(mi, nSdfs_, nJoints_) (sPoseT(mi, nSdfs_) + 24 + (nJoints_))
     __syncthreads();
@@ -264,7 +278,11 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     }
     const int d = T.dims;
     const int ld = noobs_row_len(TYPE, d);
-    float *rows = lds + sSdfOff[nModels];
+    // TPT == 0: the outer product runs on the matrix cores (systems of at most 32 dimensions, MfmaAcc), else on 4x4 VALU tiles; the
+    // intersection terms keep the matrix-core block in LDS between flushes (mfma_lds_floats ahead of the row buffer)
+    constexpr bool ACC_LDS = NOOBS_ACC_LDS && TPT == 0 && (TYPE == TERM_SELF || TYPE == TERM_INTER);
+    float *accLds = lds + __builtin_amdgcn_readfirstlane(sSdfOff[nModels]);
+    float *rows = accLds + (ACC_LDS ? mfma_lds_floats(T.dims) : 0);
     int *waveCnt = reinterpret_cast<int *>(rows + NOOBS_ROWS * ld);
     int *sPot = waveCnt + 8;            // the self term's potential-intersection matrix (when it fits)
     // reduced poses: scratch for the full Jacobian of a parked point before its reduction (one row per parked point)
@@ -331,12 +349,13 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         }
     }
     NOOBS_STAMP(0);
-    // TPT == 0: the outer product runs on the matrix cores (systems of at most 32 dimensions, MfmaAcc), else on 4x4 VALU tiles
-    std::conditional_t<TPT == 0, MfmaAcc<NE_BLOCK>, TileAcc<NE_BLOCK, (TPT > 0 ? TPT : 1)>> acc;
+    std::conditional_t<TPT == 0, MfmaAcc<NE_BLOCK, ACC_LDS>, TileAcc<NE_BLOCK, (TPT > 0 ? TPT : 1)>> acc;
+    if constexpr (TPT == 0) acc.cLds = accLds;
     acc.init(d);
     if constexpr (TPT == 0) acc.dims = d;
     NOOBS_STAMP(1);
     constexpr bool WEIGHTED = term_weighted(TYPE);
+    constexpr bool DEFER_GRAD = (TYPE == TERM_SELF && NOOBS_DEFER_GRAD_SELF) || (TYPE == TERM_INTER && NOOBS_DEFER_GRAD_INTER);
     constexpr bool UPD = TYPE == TERM_PRIORS_UPD;
     const int lOff = tile_l_off(d, WEIGHTED);
     double errInactive = 0.0;       // contact priors: _error of priors that contribute no row
@@ -353,7 +372,30 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
             f3 pm, gs;
             pm.x = row[0]; pm.y = row[1]; pm.z = row[2]; gs.x = row[3]; gs.y = row[4]; gs.z = row[5];
             const float residual = row[6];
-            const int packed = __float_as_int(row[7]);
+            const int packed = WEIGHTED ? __float_as_int(row[7]) : (__float_as_int(row[7]) & 0xff);
+            if constexpr (DEFER_GRAD) {
+                // intersections park the hit's grid coordinates (in gs): three of the row's lanes look up one central difference each
+                // (sdf_gradient's six lookups, intersection.cu:117-131 / 206-222), the lookups of all pending rows in flight together
+                // instead of one divergent gather chain per tile with a hit; then the rotation into the source model's frame
+                const int hit = (__float_as_int(row[7]) >> 8) & 0xff;
+                const ModelView &hm = (TYPE == TERM_SELF) ? src : dst;
+                const SdfDev &sd = hm.sdfs[hit];
+                float comp = 0.0f;
+                if (q < 3) {
+                    const float *data = hm.grids + sd.dataOff;
+                    f3 qp = gs, qm = gs;
+                    if (q == 0) { qp.x = gs.x + 1.0f; qm.x = gs.x - 1.0f; }
+                    else if (q == 1) { qp.y = gs.y + 1.0f; qm.y = gs.y - 1.0f; }
+                    else { qp.z = gs.z + 1.0f; qm.z = gs.z - 1.0f; }
+                    const float fp = sdf_lookup<CNT_INTER>(data, sd.dimx, sd.dimy, sd.nbx, sd.nby, qp);
+                    const float fm = sdf_lookup<CNT_INTER>(data, sd.dimx, sd.dimy, sd.nbx, sd.nby, qm);
+                    comp = 0.5f * (fp - fm);
+                }
+                const int l0 = (int)(threadIdx.x & 63u) & ~3;
+                f3 gf; gf.x = __shfl(comp, l0); gf.y = __shfl(comp, l0 + 1); gf.z = __shfl(comp, l0 + 2);
+                const f3 gd = se3_rotate(sTf(TYPE == TERM_SELF ? T.src : T.dst) + 12 * hm.nFrames + 12 * hm.sdfFrame[hit], gf);
+                gs = (TYPE == TERM_SELF) ? gd : se3_rotate(sT_ds + 12, gd);
+            }
             if constexpr (WEIGHTED) {
                 // subJ = [ dot(grad_sm, J3D_src) | -dot(grad_dm, J3D_dst) ] placed at the models' global offsets (:110-126)
                 f3 pdm, gdm;
@@ -467,9 +509,13 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                     const Collision col = tileOk ? first_collision_masked(src, sTf(T.src), pm, sSph(T.src), allowed, tileLoop)
                                                  : first_collision(src, sTf(T.src), pm, potPtr, srcGrid, sSph(T.src));
                     if (col.hit) {
-                        const SdfDev &s = src.sdfs[col.dstGrid];
-                        const f3 gf = sdf_gradient<CNT_INTER>(src.grids, s, col.vg);
-                        gs = se3_rotate(sTf(T.src) + 12 * src.nFrames + 12 * src.sdfFrame[col.dstGrid], gf);
+                        if constexpr (DEFER_GRAD) {     // the gradient is looked up when the row is built (flush)
+                            gs = col.vg; dstFrame = col.dstGrid;
+                        } else {
+                            const SdfDev &s = src.sdfs[col.dstGrid];
+                            const f3 gf = sdf_gradient<CNT_INTER>(src.grids, s, col.vg);
+                            gs = se3_rotate(sTf(T.src) + 12 * src.nFrames + 12 * src.sdfFrame[col.dstGrid], gf);
+                        }
                         residual = col.residual;
                         active = true;
                     }
@@ -484,10 +530,14 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                     const Collision col = tileOk ? first_collision_masked(dst, sTf(T.dst), vdm, sSph(T.dst), allowed, tileLoop)
                                                  : first_collision(dst, sTf(T.dst), vdm, nullptr, 0, sSph(T.dst));
                     if (col.hit) {
-                        const SdfDev &s = dst.sdfs[col.dstGrid];
-                        const f3 gf = sdf_gradient<CNT_INTER>(dst.grids, s, col.vg);
-                        const f3 gd = se3_rotate(sTf(T.dst) + 12 * dst.nFrames + 12 * dst.sdfFrame[col.dstGrid], gf);
-                        gs = se3_rotate(sT_ds + 12, gd);
+                        if constexpr (DEFER_GRAD) {
+                            gs = col.vg; dstFrame = col.dstGrid;
+                        } else {
+                            const SdfDev &s = dst.sdfs[col.dstGrid];
+                            const f3 gf = sdf_gradient<CNT_INTER>(dst.grids, s, col.vg);
+                            const f3 gd = se3_rotate(sTf(T.dst) + 12 * dst.nFrames + 12 * dst.sdfFrame[col.dstGrid], gf);
+                            gs = se3_rotate(sT_ds + 12, gd);
+                        }
                         residual = col.residual;
                         active = true;
                     }
@@ -673,7 +723,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
                                           ((int)folded << 26));
                     e[8] = pdm.x; e[9] = pdm.y; e[10] = pdm.z; e[11] = gdm.x; e[12] = gdm.y; e[13] = gdm.z; e[14] = weight; e[15] = E;
                 } else {
-                    e[7] = __int_as_float(srcFrame);
+                    e[7] = __int_as_float(srcFrame | (dstFrame << 8));       // intersections: dstFrame carries the SDF that was hit
                 }
             }
             pending += take; base += take;
@@ -699,6 +749,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
     NOOBS_STAMP(6);
 #undef sTf
 #undef sSph
+#undef uniOff
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -1133,7 +1184,8 @@ int dartk_noobs_create_reduced(int nModels, const dartk_model_t *models, const d
         T.tiles = (type == TERM_SELF) ? t->d_tileMeta[src] : nullptr;
         if (T.S > SMax) SMax = T.S;
         const int ld = noobs_row_len(type, dims);
-        const size_t cullFloats = (type == TERM_SELF || type == TERM_INTER) ? 2 + 10 * (size_t)((tiles + T.nBlocks - 1) / T.nBlocks) : 0;   // masks + splits
+        size_t cullFloats = (type == TERM_SELF || type == TERM_INTER) ? 2 + 10 * (size_t)((tiles + T.nBlocks - 1) / T.nBlocks) : 0;   // masks + splits
+        if ((type == TERM_SELF || type == TERM_INTER) && dims <= 32) cullFloats += mfma_lds_floats(dims);      // the matrix-core block (ACC_LDS)
         t->ldsTerm[nTerms - 1] = sizeof(float) * ((size_t)ldsModels + (size_t)NOOBS_ROWS * ld + 8 + (type == TERM_SELF ? t->potLdsInts : 0) +
                                                   (P.anyReduced && !term_weighted(type) ? (size_t)NOOBS_ROWS * (P.maxFullDims | 1) : 0) + cullFloats);
     };

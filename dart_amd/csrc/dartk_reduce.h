@@ -10,6 +10,7 @@
 // workgroup processes, are written once per workgroup to a [nBlocks][S] slab, and a second tiny kernel adds
 // the slabs in fp64 in a fixed order: bitwise reproducible, no float atomics.
 #pragma once
+#include <type_traits>
 
 #include "dartk_internal.h"
 
@@ -234,16 +235,32 @@ struct TileAcc {
 // entry M[i][c], i < 32, c < 32, is the SAME chain TileAcc forms, bit for bit. One wave issues one instruction per two rows instead
 // of ~36 (reads + FMAs of its 4x4 tiles). What a 32 x 32 block cannot hold -- J^T J columns 30, 31 (c = 32, 33) and, for d = 32, the e
 // slot (i = 32) -- are at most four chains, kept by four lanes of the workgroup's second wave. BLOCK must be 128.
-template <int BLOCK>
+// LDSC: the 32 x 32 block lives in LDS between accumulate() calls (register e of lane l at cLds[64 e + l]; only the registers that
+// hold a row i <= d, mfma_lds_floats(d) floats -- A is zero for i > d, so the others stay exactly zero) and
+// is in registers only while the chain runs -- for kernels whose other phases need the 16 registers (the intersection terms: rows
+// are rare there and the test loop spilled to scratch with the block resident). Same instructions on the same values in the same
+// order: bit-identical to the register-resident form.
+__host__ __device__ inline int mfma_lds_regs(int d) { return 4 * (d / 8 + 1) < 16 ? 4 * (d / 8 + 1) : 16; }     // rows 8g .. 8g+7 sit in registers 4g .. 4g+3
+__host__ __device__ inline int mfma_lds_floats(int d) { return 64 * mfma_lds_regs(d); }
+template <int BLOCK, bool LDSC = false>
 struct MfmaAcc {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
-    f32x16 c;
+    struct Empty {};
+    std::conditional_t<LDSC, Empty, f32x16> c;
+    float *cLds;            // LDSC only
     float extra;            // leftover chain of this thread (second wave, lanes 0..3)
     int ei, ec;             // its operands: L index, R index; ei < 0: none
 
     __device__ __forceinline__ void init(int d, int tid = (int)threadIdx.x) {
+        if constexpr (LDSC) {
+            if (tid < 64) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) c[e] = 0.0f;
+                for (int e = 0; e < 16; ++e) if (e < mfma_lds_regs(d)) cLds[64 * e + tid] = 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) c[e] = 0.0f;
+        }
         extra = 0.0f; ei = -1; ec = 0;
         const int q = tid - 64;
         if (q >= 0 && q < 4) {
@@ -263,10 +280,23 @@ struct MfmaAcc {
             const int half = tid >> 5, col = tid & 31;
             const int dTop = dims;
             const float *pa = rows + half * ld + lOff + col, *pb = rows + half * ld + col;
+            f32x16 acc;
+            if constexpr (LDSC) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = (e < mfma_lds_regs(dTop)) ? cLds[64 * e + tid] : 0.0f;
+            } else {
+                acc = c;
+            }
             for (int p = 0; p < n; p += 2, pa += 2 * ld, pb += 2 * ld) {
                 float a = 0.0f, b = 0.0f;
                 if (p + half < n) { a = (col <= dTop) ? *pa : 0.0f; b = *pb; }
-                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+            if constexpr (LDSC) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) if (e < mfma_lds_regs(dTop)) cLds[64 * e + tid] = acc[e];
+            } else {
+                c = acc;
             }
         } else if (ei >= 0) {
             const float *pl = rows + lOff + ei, *pr = rows + ec;
@@ -284,10 +314,14 @@ struct MfmaAcc {
             const int half = tid >> 5;
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                if ((e & 3) + 8 * (e >> 2) + 4 * half == d) c[e] = (float)((double)c[e] + v);
+                if ((e & 3) + 8 * (e >> 2) + 4 * half == d) {
+                    if constexpr (LDSC) cLds[64 * e + tid] = (float)((double)cLds[64 * e + tid] + v);
+                    else c[e] = (float)((double)c[e] + v);
+                }
         }
     }
 
+    // (LDSC: every accumulate() ends in a workgroup barrier of the caller's before store() runs; wave 0 reads its own entries anyway)
     __device__ __forceinline__ void store(float *slab, int d) const {
         const int S = sys_size(d);
         const int tid = (int)threadIdx.x;
@@ -300,7 +334,10 @@ struct MfmaAcc {
                 if (i < d && cc == 0) o = i;
                 else if (i == d && cc == 1) o = S - 1;
                 else if (i < d && cc >= 2 && cc - 2 <= i) o = d + ((i * (i + 1)) >> 1) + (cc - 2);
-                if (o >= 0) slab[o] = c[e];
+                if (o >= 0) {
+                    if constexpr (LDSC) slab[o] = cLds[64 * e + tid];
+                    else slab[o] = c[e];
+                }
             }
         } else if (ei >= 0) {
             slab[ei == d ? S - 1 : d + ((ei * (ei + 1)) >> 1) + (ec - 2)] = extra;
