@@ -236,6 +236,7 @@ def _load(path):
         "dartk_profile_begin": [],
         "dartk_profile_end": [c_float_p, c_int_p],
         "dartk_optimize_pose": [vp, vp, vp, C.c_int, C.c_int, C.POINTER(OptOptions), vp, C.c_int, vp, vp, vp, vp, vp],
+        "dartk_optimize_pose_batch": [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.POINTER(OptOptions), vp, C.c_int, vp, vp, vp, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)

@@ -87,6 +87,22 @@ def config2(width=640, height=480):
     return _articulated("C2-allegro", "allegro", width, height, 0.45, np.random.default_rng(SEED))
 
 
+def tracking_frames(sc, n, seed=SEED + 100):
+    """n independent frames of a single-model tracking scene (a recorded sequence's stand-in for Optimizer::optimizePose looped over
+    frames): frame 0 is the scene itself, frame f > 0 a seeded perturbation of its true pose with its own perturbed start pose.
+    Returns (true_T [n, 12], true_joints [n, nJ], init_T [n, 12], init_joints [n, nJ])."""
+    m = sc.host_model
+    nj = len(sc.true_joints)
+    lim = np.asarray(m.joint_limits, dtype=np.float64).reshape(-1, 2) if nj else None
+    tT, tj, iT, ij = [sc.true_T_mc], [sc.true_joints], [sc.init_T_mc], [sc.init_joints]
+    for f in range(1, n):
+        rng = np.random.default_rng(seed + f)
+        T, j = _perturb(sc.true_T_mc, sc.true_joints.astype(np.float64), lim, rng, 0.02 * rng.uniform(0.2, 1.0), 6.0 * rng.uniform(0.2, 1.0), 0.1)
+        T0, j0 = _perturb(T, j.astype(np.float64), lim, rng, 0.012, 3.0, 0.1)
+        tT.append(T); tj.append(j); iT.append(T0); ij.append(j0)
+    return (np.stack(tT).astype(F), np.stack(tj).astype(F).reshape(n, nj), np.stack(iT).astype(F), np.stack(ij).astype(F).reshape(n, nj))
+
+
 def config2_left_hand(width=640, height=480):
     """The asset-faithful articulated model (primitives straight from models/leftHand/leftHand.xml)."""
     return _articulated("C2-leftHand", "left_hand", width, height, 0.45, np.random.default_rng(SEED + 1))

@@ -179,10 +179,19 @@ __device__ __forceinline__ void fused_obs2mod_tile(int tile, const FusedObs2ModA
     acc.store(slabs + (size_t)tile * sys_size(d), sys_size(d));
     if (threadIdx.x == 0 && nActive) atomicAdd(count, nActive);
 }
+// (grid.y = frame of a batch: maps fb.vert float4 apart, index lists fb.pts ints, counters fb.counts ints, valid-pixel totals 1 int,
+// slabs gridDim.x partial systems apart; one frame: all strides 0)
 template <int PPT>
 __global__ void __launch_bounds__(NE_BLOCK)
-fused_obs2mod_kernel(FusedObs2ModArgs fa, ModelView m) {
+fused_obs2mod_kernel(FusedObs2ModArgs fa, ModelView m_in, FrameBatch fb) {
     extern __shared__ float lds[];
+    ModelView m = m_in;
+    const size_t f = blockIdx.y;
+    select_frame(m, (int)f);
+    fa.vert += f * fb.vert; fa.norm += f * fb.vert;
+    fa.validIdx += f * fb.pts; fa.nValidPtr += f;
+    fa.count += f * fb.counts;
+    fa.slabs += f * gridDim.x * sys_size(6 + m.nJoints);
     fused_obs2mod_tile<PPT>(blockIdx.x, fa, m, lds);
 }
 
@@ -224,7 +233,9 @@ struct ReduceTerm {
     const int *nItems; int itemsPerBlock; // when set: only the first ceil(*nItems / itemsPerBlock) slabs were written
     float *out;
 };
-struct ReduceArgs { ReduceTerm t[4]; };
+// grid.z = frame of a batch: a frame's slabs follow the previous frame's (nBlocks * S floats), its count lies countStride ints, its
+// item total 1 int and its output outStride floats after the previous frame's
+struct ReduceArgs { ReduceTerm t[4]; int countStride, outStride; };
 
 // Fixed-order fp64 sum of the partial systems, spread over the chip: workgroup (x, term) owns 64 outputs of one
 // term; its 4 waves each sum a quarter of the slabs and the quarters are combined in a fixed order. Bitwise
@@ -232,7 +243,14 @@ struct ReduceArgs { ReduceTerm t[4]; };
 __global__ void __launch_bounds__(64 * GN_REDUCE_SEGS)
 gn_reduce_kernel(ReduceArgs a) {
     __shared__ double part[GN_REDUCE_SEGS][64];
-    const ReduceTerm t = a.t[blockIdx.y];
+    ReduceTerm t = a.t[blockIdx.y];
+    {
+        const size_t f = blockIdx.z;
+        if (t.slabs) t.slabs += f * (size_t)t.nBlocks * t.S;
+        if (t.count) t.count += f * a.countStride;
+        if (t.nItems) t.nItems += f;
+        t.out += f * a.outStride;
+    }
     const int o = blockIdx.x * 64 + (threadIdx.x & 63);
     const int q = threadIdx.x >> 6;
     if (blockIdx.x * 64 >= t.S) return;
@@ -272,6 +290,7 @@ struct SolveArgs {
     float regularization, lmLambda;
     float *iterInfo;        // 8 floats or null
     float *firstSystem;     // 3 packed systems or null
+    int sysStride, countStride, infoStride;     // a batch (blockIdx.x = frame): floats / ints / floats between two frames; else 0
 };
 
 __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -603,8 +622,19 @@ __device__ __forceinline__ float assemble_solve_regs(const SolveArgs &a, int d, 
 
 // assemble + solve + update + forward kinematics (optimizer.cpp:482-518), ONE wave.
 __global__ void __launch_bounds__(64)
-gn_solve_single_kernel(ModelView m, SolveArgs a) {
+gn_solve_single_kernel(ModelView m_in, SolveArgs a_in) {
     extern __shared__ float lds[];
+    ModelView m = m_in;
+    SolveArgs a = a_in;
+    {   // frame of a batch (one wave per frame); a single call: frame 0, strides 0
+        const size_t f = blockIdx.x;
+        select_frame(m, (int)f);
+        if (a.sysA) a.sysA += f * a.sysStride;
+        if (a.sysB) a.sysB += f * a.sysStride;
+        if (a.sysC) a.sysC += f * a.sysStride;
+        a.countA += f * a.countStride; a.countB += f * a.countStride;
+        if (a.iterInfo) a.iterInfo += f * a.infoStride;
+    }
     const int d = 6 + m.nJoints;
     const int ad = d - 6;
     const int S = sys_size(d), Sa = sys_size(ad);
@@ -697,6 +727,186 @@ gn_solve_single_kernel(ModelView m, SolveArgs a) {
 
 static size_t solve_lds_bytes(int d, int nFrames) {
     return sizeof(float) * (size_t)(d * (d + 2) + 4 * d + 12 * nFrames + 8);
+}
+
+// dartk_optimize_pose_batch: poses in (mode 0: T_mc, its inverse, the joints, forward kinematics as MirroredModel::setPose does) and
+// out (mode 1) of the frames' pose records; one wave per frame
+__global__ void __launch_bounds__(64)
+gn_batch_pose_kernel(ModelView m_in, float *__restrict__ T_mcs, float *__restrict__ joints, int mode) {
+    extern __shared__ float lds[];
+    ModelView m = m_in;
+    const int f = blockIdx.x, lane = threadIdx.x;
+    select_frame(m, f);
+    float *T = T_mcs + (size_t)f * 12;
+    float *j = joints ? joints + (size_t)f * m.nJoints : nullptr;
+    if (mode == 1) {
+        if (lane < 12) T[lane] = m.T_mc[lane];
+        if (lane < m.nJoints) j[lane] = m.joints[lane];
+        return;
+    }
+    if (lane == 0) {
+        float A[12], inv[12];
+        for (int i = 0; i < 12; ++i) A[i] = T[i];
+        se3_invert(A, inv);
+        for (int i = 0; i < 12; ++i) { m.T_mc[i] = A[i]; m.T_cm[i] = inv[i]; }
+    }
+    const float value = lane < m.nJoints ? j[lane] : 0.0f;
+    if (lane < m.nJoints) m.joints[lane] = value;
+    const FkTables t = fk_prefetch(m);
+    fk_wave(m, 0, lds, t, value);
+}
+
+// per-device scratch of the batched loop (grown on demand, kept until the process ends)
+struct BatchScratch { void *p; size_t bytes; };
+static BatchScratch g_batchScratch[16];
+static int batch_scratch(size_t bytes, void **out) {
+    int dev = 0;
+    DARTK_HIP(hipGetDevice(&dev));
+    DARTK_REQUIRE(dev >= 0 && dev < 16, "device index %d out of range", dev);
+    if (g_batchScratch[dev].bytes < bytes) {
+        if (g_batchScratch[dev].p) { DARTK_HIP(hipDeviceSynchronize()); DARTK_HIP(hipFree(g_batchScratch[dev].p)); }
+        g_batchScratch[dev].p = nullptr; g_batchScratch[dev].bytes = 0;
+        DARTK_HIP(hipMalloc(&g_batchScratch[dev].p, bytes));
+        g_batchScratch[dev].bytes = bytes;
+    }
+    *out = g_batchScratch[dev].p;
+    return DARTK_OK;
+}
+
+// One chunk of dartk_optimize_pose_batch: nf frames side by side through the kernels of dartk_optimize_pose (grid.y / grid.z =
+// frame; reduction and solve: per frame what the single call launches), on one stream.
+static int optimize_pose_chunk(Model *mod, int nf, const float *d_vert, const float *d_norm, int width, int height, const dartk_opt_options *o,
+                               const float *d_cloud, int nCloud, const int32_t *d_potential, float *d_T_mcs, float *d_joints,
+                               float *d_iterInfo, hipStream_t st) {
+    const bool useA = o->lambdaObsToMod > 0, useB = o->lambdaModToObs > 0;
+    const bool useC = o->lambdaIntersection > 0 && nCloud > 0;
+    const ModelView &m0 = mod->v;
+    const int d = 6 + m0.nJoints, S = sys_size(d), Sa = sys_size(d - 6);
+    const int nPix = width * height, nPred = useB ? o->predWidth * o->predHeight : 0;
+    Workspace *ws;
+    int rc = get_workspace(&ws);
+    if (rc) return rc;
+    // the partial systems of a frame: the same number of slabs per term as the single call (the sums keep their order)
+    const int nBlocksA = (nPix + NE_BLOCK - 1) / NE_BLOCK;
+    const int tilesB = (nPred + NE_BLOCK - 1) / NE_BLOCK;
+    const int nBlocksB = tilesB < GN_MAX_BLOCKS ? tilesB : GN_MAX_BLOCKS;
+    const int tilesC = (nCloud + NE_BLOCK - 1) / NE_BLOCK;
+    const int nBlocksC = tilesC < GN_MAX_BLOCKS ? tilesC : GN_MAX_BLOCKS;
+    const size_t slabA = useA ? (size_t)nBlocksA * S : 0, slabB = useB ? (size_t)nBlocksB * S : 0, slabC = useC ? (size_t)nBlocksC * Sa : 0;
+    rc = ensure_partials(ws, (size_t)nf * (slabA + slabB + slabC));
+    if (rc) return rc;
+    float *slabsA = ws->partials, *slabsB = slabsA + nf * slabA, *slabsC = slabsB + nf * slabB;
+    const int nVcBlocks = (nPix + VC_BLOCK - 1) / VC_BLOCK;
+    rc = ensure_valid_idx(ws, (size_t)nf * ((size_t)nPix + nVcBlocks + 1));
+    if (rc) return rc;
+    int *validIdx = ws->validIdx, *vcWork = validIdx + (size_t)nf * nPix, *d_nValid = vcWork + (size_t)nf * nVcBlocks;
+
+    // one allocation: [pose records | observation SDFs | distance-transform scratch | prediction maps | T_gc | systems | counters]
+    const size_t rec = 24 + 24 * (size_t)m0.nFrames + (size_t)(m0.nJoints > 0 ? m0.nJoints : 1);
+    const int sysStride = 2 * S + Sa;
+    size_t total = 0;
+    auto take = [&](size_t bytes) { size_t at = (total + 255) / 256 * 256; total = at + bytes; return at; };
+    const size_t o_pose = take(sizeof(float) * rec * nf);
+    const size_t o_obs = take(sizeof(float) * mod->obsVoxels * nf * (useB ? 1 : 0));
+    const size_t o_tmp = take(sizeof(float) * mod->obsVoxels * nf * (useB ? 1 : 0));
+    const size_t o_pred = take(sizeof(float) * 4 * (size_t)nPred * nf);
+    const size_t o_tgc = take(sizeof(float) * 12 * nf);
+    const size_t o_sys = take(sizeof(float) * (size_t)sysStride * nf);
+    const size_t o_cnt = take(sizeof(int) * 2 * (size_t)nf);
+    void *base = nullptr;
+    rc = batch_scratch(total, &base);
+    if (rc) return rc;
+    auto at = [&](size_t off) { return reinterpret_cast<float *>((char *)base + off); };
+    Model view = *mod;          // the handle's static tables with per-frame pose / observation-SDF arrays
+    ModelView &m = view.v;
+    float *p = at(o_pose);
+    m.T_mc = p; m.T_cm = p + 12; m.T_mf = p + 24; m.T_fm = p + 24 + 12 * m.nFrames; m.joints = p + 24 + 24 * m.nFrames;
+    m.poseStride = (int)rec;
+    if (useB) { m.obsData = at(o_obs); m.obsStride = (int)mod->obsVoxels; view.dtTmp = at(o_tmp); }
+    float *d_pred = at(o_pred), *d_T_gc = at(o_tgc);
+    float *sysA = at(o_sys), *sysB = sysA + S, *sysC = sysB + S;
+    int *cntA = reinterpret_cast<int *>((char *)base + o_cnt), *cntB = cntA + 1;
+    const size_t traceFloats = useB ? ray_trace_floats(o->predWidth, o->predHeight, m.nSdfs) : 0;
+    const FrameBatch fb = {nf, 2, sysStride, 12, (size_t)nPix, (size_t)nPred, traceFloats, (size_t)nPix};
+    BatchScope scope(fb);
+
+    const size_t ldsS = solve_lds_bytes(d, m.nFrames);
+    const size_t ldsA = sizeof(float) * (24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8);
+    DARTK_REQUIRE(ldsA <= 160 * 1024 && ldsS <= 160 * 1024, "LDS requirement exceeds 160 KiB");
+    if (ldsS > 64 * 1024)
+        DARTK_HIP(hipFuncSetAttribute((const void *)gn_solve_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS));
+    hipLaunchKernelGGL(gn_batch_pose_kernel, dim3(nf), dim3(64), sizeof(float) * 12 * (size_t)(m.nFrames + 1), st, m, d_T_mcs, d_joints, 0);
+    DARTK_HIP(hipGetLastError());
+    DARTK_HIP(hipMemsetAsync(cntA, 0, sizeof(int) * 2 * (size_t)nf, st));
+    if (useB) {     // generateObsSdf with every frame's start pose; T_obsSdf_camera frozen (optimizer.cpp:445-449)
+        ProfScope ps(DARTK_PROF_OBS_SDF, st);
+        rc = gn_obs_sdf_build(d_vert, width, height, &view, o->focalLength, st, nullptr);
+        if (rc) return rc;
+        DARTK_HIP(hipMemcpy2DAsync(d_T_gc, sizeof(float) * 12, m.T_mc, sizeof(float) * rec, sizeof(float) * 12, nf, hipMemcpyDeviceToDevice, st));
+        rc = gn_raycast_reserve(traceFloats * nf);
+        if (rc) return rc;
+    }
+    if (useA && o->numIterations > 0) {
+        ProfScope ps(DARTK_PROF_OTHER, st);
+        rc = gn_valid_pixels(d_vert, nPix, nf, vcWork, validIdx, d_nValid, st);
+        if (rc) return rc;
+    }
+    const FusedObs2ModArgs fa = {(const float4 *)d_vert, (const float4 *)d_norm, validIdx, d_nValid, o->distThreshold, o->normThreshold,
+                                 o->planeOffset, o->planeNormal[0], o->planeNormal[1], o->planeNormal[2], o->huberDelta, slabsA, cntA};
+    for (int it = 0; it < o->numIterations; ++it) {
+        if (useB) {
+            rc = gn_launch_raycast_ne_mod2obs(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2), o->predWidth,
+                                              o->predHeight, 0, m, d_pred, d_T_gc, slabsB, nBlocksB, cntB, st, nullptr, false, nullptr);
+            if (rc) return rc;
+        }
+        if (useA) {
+            ProfScope ps(DARTK_PROF_FUSED_OBS2MOD, st);
+#define DARTK_LAUNCH_FUSED_B(PPT_)                                                                              \
+    do {                                                                                                        \
+        auto kfn = fused_obs2mod_kernel<PPT_>;                                                                  \
+        if (ldsA > 64 * 1024)                                                                                   \
+            DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA)); \
+        hipLaunchKernelGGL(kfn, dim3(nBlocksA, nf), dim3(NE_BLOCK), ldsA, st, fa, m, fb);                       \
+    } while (0)
+            if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_FUSED_B(3);
+            else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_FUSED_B(6);
+            else DARTK_LAUNCH_FUSED_B(20);
+#undef DARTK_LAUNCH_FUSED_B
+            DARTK_HIP(hipGetLastError());
+        }
+        if (useC) {
+            ProfScope ps(DARTK_PROF_NE_SELF, st);
+            rc = gn_launch_ne_self(d_cloud, nCloud, m, d_potential, slabsC, nBlocksC, st);
+            if (rc) return rc;
+        }
+        ReduceArgs ra = {};
+        ra.countStride = 2; ra.outStride = sysStride;
+        int nTerms = 0;
+        if (useA) ra.t[nTerms++] = ReduceTerm{slabsA, nBlocksA, S, cntA, 10, d_nValid, NE_BLOCK, sysA};
+        if (useB) ra.t[nTerms++] = ReduceTerm{slabsB, nBlocksB, S, nullptr, 0, nullptr, 0, sysB};
+        if (useC) ra.t[nTerms++] = ReduceTerm{slabsC, nBlocksC, Sa, nullptr, 0, nullptr, 0, sysC};
+        SolveArgs a;
+        a.sysA = useA ? sysA : nullptr; a.countA = cntA;
+        a.sysB = useB ? sysB : nullptr; a.countB = cntB;
+        a.sysC = useC ? sysC : nullptr;
+        a.lambdaA = o->lambdaObsToMod; a.lambdaB = o->lambdaModToObs; a.lambdaC = o->lambdaIntersection;
+        a.regularization = o->regularization; a.lmLambda = o->regularizationScaled;
+        a.iterInfo = d_iterInfo ? d_iterInfo + 8 * it : nullptr;
+        a.firstSystem = nullptr;
+        a.sysStride = sysStride; a.countStride = 2; a.infoStride = 8 * o->numIterations;
+        if (nTerms) {
+            ProfScope ps(DARTK_PROF_REDUCE, st);
+            hipLaunchKernelGGL(gn_reduce_kernel, dim3((S + 63) / 64, nTerms, nf), dim3(64 * GN_REDUCE_SEGS), 0, st, ra);
+        }
+        {
+            ProfScope ps(DARTK_PROF_SOLVE, st);
+            hipLaunchKernelGGL(gn_solve_single_kernel, dim3(nf), dim3(64), ldsS, st, m, a);
+        }
+        DARTK_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(gn_batch_pose_kernel, dim3(nf), dim3(64), 0, st, m, d_T_mcs, d_joints, 1);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
 }
 
 DARTK_COUNTER_ACCESS(gn)
@@ -837,6 +1047,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     }
     const FusedObs2ModArgs fa = {(const float4 *)d_vert, (const float4 *)d_norm, validIdx, d_nValid, o->distThreshold, o->normThreshold,
                                  o->planeOffset, o->planeNormal[0], o->planeNormal[1], o->planeNormal[2], o->huberDelta, slabsA, cntA};
+    const FrameBatch oneFrame{1, 0, 0, 0, 0, 0, 0, 0};
     TraceArgs ta = {};
     size_t ldsU = ldsA;
     if (unionAB) {
@@ -866,7 +1077,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
             auto kfn = fused_obs2mod_kernel<PPT_>;                                                              \
             if (ldsA > 64 * 1024)                                                                               \
                 DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA)); \
-            hipLaunchKernelGGL(kfn, dim3(nBlocksA), dim3(NE_BLOCK), ldsA, stA, fa, m);                          \
+            hipLaunchKernelGGL(kfn, dim3(nBlocksA), dim3(NE_BLOCK), ldsA, stA, fa, m, oneFrame);                \
         }                                                                                                       \
     } while (0)
         if (unionAB) {
@@ -901,6 +1112,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         }
         const int Sa = sys_size(d - 6);
         ReduceArgs ra = {};
+        ra.countStride = 0; ra.outStride = 0;
         int nTerms = 0;
         if (useA) ra.t[nTerms++] = ReduceTerm{slabsA, nBlocksA, S, cntA, 10, d_nValid, NE_BLOCK, sysA};
         if (useB) ra.t[nTerms++] = ReduceTerm{slabsB, nBlocksB, S, nullptr, 0, nullptr, 0, sysB};
@@ -913,6 +1125,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         a.regularization = o->regularization; a.lmLambda = o->regularizationScaled;
         a.iterInfo = d_iterInfo ? d_iterInfo + 8 * it : nullptr;
         a.firstSystem = (it == 0) ? d_firstSystem : nullptr;
+        a.sysStride = a.countStride = a.infoStride = 0;
         if (nTerms) {
             ProfScope ps(DARTK_PROF_REDUCE, st);
             hipLaunchKernelGGL(gn_reduce_kernel, dim3((S + 63) / 64, nTerms), dim3(64 * GN_REDUCE_SEGS), 0, st, ra);
@@ -924,6 +1137,42 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
         DARTK_HIP(hipGetLastError());
     }
     joinGuard.on = false;       // every iteration joined stA before its reduction; stO joined through evObs in iteration 0
+    return DARTK_OK;
+}
+
+int dartk_optimize_pose_batch(dartk_model_t h, int nFrames, const float *d_vert, const float *d_norm, int width, int height,
+                              const dartk_opt_options *o, const float *d_cloud, int nCloud, const int32_t *d_potential,
+                              float *d_T_mcs, float *d_joints, float *d_iterInfo, void *stream) {
+    Model *mod = reinterpret_cast<Model *>(h);
+    DARTK_REQUIRE(mod && d_vert && d_norm && o && d_T_mcs, "dartk_optimize_pose_batch: null argument");
+    DARTK_REQUIRE(nFrames >= 1 && nFrames <= 65535, "nFrames %d out of range [1,65535]", nFrames);
+    DARTK_REQUIRE(width > 0 && height > 0 && (long long)width * height < (1ll << 31), "bad map size %dx%d", width, height);
+    DARTK_REQUIRE(o->numIterations >= 0, "negative iteration count");
+    DARTK_REQUIRE(mod->v.nJoints == 0 || d_joints, "dartk_optimize_pose_batch: joint array missing");
+    const bool useB = o->lambdaModToObs > 0;
+    const bool useC = o->lambdaIntersection > 0 && nCloud > 0;
+    if (useB) {
+        DARTK_REQUIRE(o->predWidth > 0 && o->predHeight > 0, "mod->obs term needs a prediction size");
+        DARTK_REQUIRE(mod->obsVoxels > 0, "mod->obs term needs a model with an observation SDF");
+        if (mod->v.nSdfs > NE_BLOCK || mod->v.nSdfs > kMaxRaySdfs) {
+            set_error("dartk_optimize_pose_batch: the batched ray-cast replay needs at most %d SDFs, got %d", NE_BLOCK < kMaxRaySdfs ? NE_BLOCK : kMaxRaySdfs, mod->v.nSdfs);
+            return DARTK_ERR_UNSUPPORTED;
+        }
+    }
+    if (useC) DARTK_REQUIRE(d_cloud && d_potential, "intersection term needs a collision cloud and potential matrix");
+    // frames in chunks that bound the per-call device memory (DARTK_BATCH_CHUNK, as dartk_optimize_poses_batch)
+    const char *env = getenv("DARTK_BATCH_CHUNK");
+    int chunk = env ? atoi(env) : 64;
+    if (chunk < 1) chunk = 64;
+    hipStream_t st = as_stream(stream);
+    const size_t mapFloats = 4 * (size_t)width * height;
+    for (int f0 = 0; f0 < nFrames; f0 += chunk) {
+        const int nf = nFrames - f0 < chunk ? nFrames - f0 : chunk;
+        int rc = optimize_pose_chunk(mod, nf, d_vert + f0 * mapFloats, d_norm + f0 * mapFloats, width, height, o, d_cloud, nCloud, d_potential,
+                                     d_T_mcs + (size_t)f0 * 12, d_joints ? d_joints + (size_t)f0 * mod->v.nJoints : nullptr,
+                                     d_iterInfo ? d_iterInfo + (size_t)f0 * o->numIterations * 8 : nullptr, st);
+        if (rc) return rc;
+    }
     return DARTK_OK;
 }
 

@@ -338,7 +338,7 @@ int gn_launch_ne_self(const float *d_sites, int nSites, const ModelView &m, cons
         auto kfn = ne_self_intersection_kernel<PPT_, 0>;                                                        \
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
-        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, m, d_pot, \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks, cur_batch().n), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_sites, nSites, m, d_pot, \
                            fullDims, nullptr, nullptr, slabs);                                                  \
     } while (0)
     if (S <= NE_BLOCK) DARTK_LAUNCH_SELF(1);      // a small system: one output per thread, no idle accumulator slots

@@ -466,6 +466,10 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
     pred += (size_t)blockIdx.y * fb.pred;
     T_gc_in += (size_t)blockIdx.y * tgcStride;
     numPredictions += (size_t)blockIdx.y * fb.counts;
+    if (REPLAY) {       // the frame's slice of the trace buffer (fb.trace floats apart) and of the prediction maps
+        ra.trace += (size_t)blockIdx.y * (fb.trace / 2);
+        ra.predOut += (size_t)blockIdx.y * fb.pred;
+    }
     // hit-list form (batches): `pred` holds the frame's hits back to back, nItems[frame] of them (raycast_replay_multi_rows_kernel)
     if (nItems) nPix = nItems[(size_t)blockIdx.y * fb.counts];
     const int fullDims = 6 + m.nJoints;
@@ -781,14 +785,18 @@ int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int
     const size_t ldsBytes = ne_mod2obs_lds_bytes(m, d, 0) + sizeof(float) * (28 * (size_t)m.nSdfs + 1);
     DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
     const ReplayArgs ra = {flx, fly, ppx, ppy, width, modelNum, (const float2 *)ws->rayBuf, (float4 *)d_prediction, d_tables};
+    // a batch (dartk_optimize_pose_batch): grid.y = frame, T_gc in the per-frame table, no shared replay tables
+    const FrameBatch fb = cur_batch();
+    DARTK_REQUIRE(fb.n == 1 || !d_tables, "replay tables are per pose: a batch rebuilds them in the kernel");
+    const int tgcStride = fb.n > 1 ? fb.tab : 0;
     ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
 #define DARTK_LAUNCH_RM2O(PPT_)                                                                                 \
     do {                                                                                                        \
         auto kfn = ne_mod2obs_kernel<PPT_, 0, false, true>;                                                     \
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
-        hipLaunchKernelGGL(kfn, dim3(nBlocks), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_prediction, nPix, m.modelId, m, d_T_gc, 0.f, \
-                           d, nullptr, nullptr, slabs, d_num, ra, FrameBatch{1, 0, 0, 0, 0, 0, 0, 0}, 0, (const int *)nullptr); \
+        hipLaunchKernelGGL(kfn, dim3(nBlocks, fb.n), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_prediction, nPix, m.modelId, m, d_T_gc, 0.f, \
+                           d, nullptr, nullptr, slabs, d_num, ra, fb, tgcStride, (const int *)nullptr); \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_RM2O(3);
     else if (S <= 6 * NE_BLOCK) DARTK_LAUNCH_RM2O(6);

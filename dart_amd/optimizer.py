@@ -93,6 +93,23 @@ class Optimizer:
                                         device._ptr(self.prediction), device._ptr(info), device._ptr(first), device._stream()))
         self.iter_info, self.first_system = info, first
 
+    def optimizePoseBatch(self, model, vert, norm, T_mcs, joints, opts, collision_cloud=None, potential=None, debug=False):
+        """Optimizer::optimizePose (optimizer.cpp:423-522) for independent frames side by side (the reference loops over the frames
+        on the host): vert / norm [nFrames, h, w, 4], T_mcs [nFrames, 12] and joints [nFrames, nJoints] device tensors, updated in
+        place. Frame f's result equals optimizePose on a model set to (T_mcs[f], joints[f]). The model's own pose is untouched."""
+        n, h, w = vert.shape[:3]
+        assert vert.is_contiguous() and norm.is_contiguous() and norm.shape == vert.shape
+        assert T_mcs.shape == (n, 12) and T_mcs.dtype == torch.float32 and T_mcs.is_contiguous()
+        nj = model.dims - 6
+        assert nj == 0 or (joints.shape == (n, nj) and joints.dtype == torch.float32 and joints.is_contiguous())
+        o = opts.c_struct(0, self.pred_width, self.pred_height, self.pred_fl)
+        n_cloud = 0 if collision_cloud is None else collision_cloud.shape[0]
+        info = torch.zeros((n, max(opts.numIterations, 1), 8), dtype=torch.float32, device=vert.device) if debug else None
+        check(lib().dartk_optimize_pose_batch(model.handle, n, device._ptr(vert), device._ptr(norm), w, h, C.byref(o),
+                                              device._ptr(collision_cloud), n_cloud, device._ptr(potential), device._ptr(T_mcs),
+                                              device._ptr(joints) if nj else None, device._ptr(info), device._stream()))
+        self.iter_info = info
+
 
 def depth_to_vertices(depth, pp, fl, depth_range=(0.1, 5.0), out=None):
     """PointCloudSource::projectDepthMap -> depthToVertices (point_cloud_src.h:261-285). `out`: an existing [h, w, 4] vertex

@@ -301,6 +301,24 @@ int dartk_optimize_pose(dartk_model_t m, const float *d_vert, const float *d_nor
                         const int32_t *d_potentialIntersection, float *d_prediction, float *d_iterInfo,
                         float *d_firstSystem, void *stream);
 
+/* Optimizer::optimizePose (optimizer.cpp:423-522) for nFrames INDEPENDENT frames of one model in one call (BASELINE configs[1]
+ * over a recorded sequence: the reference loops over the frames on the host, one optimizePose each). Every launch covers all
+ * frames (grid.y = frame; the LDL^T solve: one wave per frame) with the kernels of dartk_optimize_pose and, per frame, the same
+ * partial systems summed in the same order: frame f's result equals, bit for bit, dartk_optimize_pose on a model set to
+ * (d_T_mcs[f], d_joints[f]) -- no atomically appended list is involved on this path. The frames share the model's SDFs and
+ * tables, the options, the collision cloud and the potential matrix, and differ in
+ *   d_vert / d_norm   [nFrames][height*width*4]  observation maps, frame-major
+ *   d_T_mcs           [nFrames][12]              camera->model transforms, in/out
+ *   d_joints          [nFrames][nJoints]         in/out (NULL for a rigid model)
+ * Optional d_iterInfo [nFrames][numIterations][8] as for dartk_optimize_pose. The model handle's own pose and observation SDF
+ * are not touched. Frames are processed in chunks of 64 (DARTK_BATCH_CHUNK), which bounds the device memory held for the
+ * frames' partial systems, traces, prediction maps and observation SDFs. Models of more than 128 SDFs: DARTK_ERR_UNSUPPORTED
+ * when the mod->obs term is on. */
+int dartk_optimize_pose_batch(dartk_model_t m, int nFrames, const float *d_vert, const float *d_norm, int width, int height,
+                              const dartk_opt_options *opts, const float *d_collisionCloud, int nCloud,
+                              const int32_t *d_potentialIntersection, float *d_T_mcs, float *d_joints, float *d_iterInfo,
+                              void *stream);
+
 /* ------------------------------------------------------------------ ContactGrasp refinement (TrackerNoObs / OptimizerNoObs) */
 /* ContactPrior (optimization/priors.h:35-91): contact point in the source SDF's frame, attracted to (or, inverted,
  * repelled from) the nearest SDF of the destination model. */
