@@ -60,6 +60,8 @@ def _profile_json(name):
 PMC_TRAFFIC = _profile_json("pmc_traffic.json")                 # HBM bytes per launch (FETCH_SIZE / WRITE_SIZE passes, corrected)
 PMC_TRAFFIC_BATCH = _profile_json("pmc_traffic_batch.json")     # the same for the 64-frame launches of the config-5 batch
 ROCPROF = _profile_json("kernel_durations.json")                # --kernel-trace: calls / median / average duration per kernel
+ROCPROF_POSE_BATCH = _profile_json("kernel_durations_pose_batch.json")   # the same of a pass over the single-model frame batch alone
+PMC_TRAFFIC_POSE_BATCH = _profile_json("pmc_traffic_pose_batch.json")
 L2_RATES = _profile_json("l2_hit_rate.json")                    # TCC_HIT / MISS / REQ pass
 LIMITERS = _profile_json("kernel_limiters.json")                # what the counters say bounds each kernel (+ the evidence)
 # bench kernel class -> (kernel name in the rocprof tables, regular expression on its template arguments or None)
@@ -80,13 +82,13 @@ ROCPROF_KERNELS = {
 }
 
 
-def rocprof_stats(kernel, batch, retry=True):
+def rocprof_stats(kernel, batch, retry=True, table=None):
     """calls / median / average launch duration of `kernel` (a ROCPROF_KERNELS class) in the committed rocprofv3 kernel trace;
     batch: the launches with more than one grid row (frames / candidates) or the single-row ones. None when not collected."""
     import re
     tot_calls, avg_sum, meds = 0, 0.0, []
     for base, targs in ROCPROF_KERNELS.get(kernel, [(kernel, None)]):
-        for key, v in ROCPROF.items():
+        for key, v in (ROCPROF if table is None else table).items():
             name, is_batch = (key[:-6], True) if key.endswith("@batch") else (key, False)
             if is_batch != batch:
                 continue
@@ -98,9 +100,10 @@ def rocprof_stats(kernel, batch, retry=True):
             meds.append((v["median_us"], v["calls"]))
     if not tot_calls:
         # kernels whose second grid dimension is not a frame (gn_reduce_kernel: term; noobs_solve_kernel: candidates in x)
-        return rocprof_stats(kernel, not batch, False) if retry else None
+        return rocprof_stats(kernel, not batch, False, table) if retry else None
     return {"calls": tot_calls, "avg_us": round(avg_sum / tot_calls, 2),
-            "median_us": round(sum(m * c for m, c in meds) / tot_calls, 2), "source": "profiles/kernel_durations.json"}
+            "median_us": round(sum(m * c for m, c in meds) / tot_calls, 2),
+            "source": "profiles/kernel_durations.json" if table is None else "profiles/kernel_durations_pose_batch.json"}
 
 
 def l2_hit_rate(kernel):
@@ -167,7 +170,7 @@ def count_lookups(fn):
     return [int(v) for v in cnt]
 
 
-def roofline_entry(name, bytes_per_launch, lookups_per_launch, per_launch_us, batch=False, traffic_table=None):
+def roofline_entry(name, bytes_per_launch, lookups_per_launch, per_launch_us, batch=False, traffic_table=None, rocprof_table=None):
     """One kernel's roofline figures. achieved = algorithmic bytes of the work performed / the launch duration measured live with
     HIP events on the launch stream. `bound` names the roof the fraction is priced against (HBM bandwidth: every kernel of this
     path moves bytes, none is a GEMM); `limiter` says what the committed counter passes show actually bounds the kernel
@@ -178,7 +181,7 @@ def roofline_entry(name, bytes_per_launch, lookups_per_launch, per_launch_us, ba
     ach = bytes_per_launch / (us * 1e-6) / 1e9
     traffic = pmc_traffic(name, PMC_TRAFFIC if traffic_table is None else traffic_table)
     lim = LIMITERS.get(name + ("@batch" if batch and (name + "@batch") in LIMITERS else ""), {})
-    rp = rocprof_stats(name, batch)
+    rp = rocprof_stats(name, batch, True, rocprof_table)
     e = {"bound": "hbm", "limiter": lim.get("limiter"), "limiter_evidence": lim.get("evidence"), "kernel": name,
          "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -191,12 +194,12 @@ def roofline_entry(name, bytes_per_launch, lookups_per_launch, per_launch_us, ba
     return e
 
 
-def per_step_from_rocprof(launches, batch, chain, step_seconds):
+def per_step_from_rocprof(launches, batch, chain, step_seconds, table=None):
     """us per step per kernel class = committed rocprofv3 median x launches per step (live launch counts); `chain` lists the classes
     that run back to back on the caller's stream: their sum must fit into the measured step."""
     out = {}
     for k, n in launches.items():
-        rp = rocprof_stats(k, batch)
+        rp = rocprof_stats(k, batch, True, table)
         if rp:
             out[k] = round(rp["median_us"] * n, 2)
     if not out:
@@ -268,6 +271,9 @@ def main():
     ap.add_argument("--multi-steps", type=int, default=2)
     ap.add_argument("--frames", type=int, default=256, help="frames of the config-5 batch (sharded by index over the ranks)")
     ap.add_argument("--no-tracking", action="store_true", help="profiling aid: skip the headline leg's timed loop")
+    ap.add_argument("--no-pose-batch", action="store_true", help="skip the single-model frame-batch leg (dartk_optimize_pose_batch)")
+    ap.add_argument("--pose-frames", type=int, default=256, help="frames of the single-model batch (sharded by index over the ranks)")
+    ap.add_argument("--pose-steps", type=int, default=3)
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="test aid for a 1-GPU box: every rank uses cuda:0 and the ranks talk over gloo (RCCL refuses two ranks on one device); "
                          "exercises the sharding / gather / max-over-ranks code of the multi-GPU launch, the numbers mean nothing")
@@ -481,6 +487,98 @@ def main():
             cpu_baseline = {"value": round(many, 3), "unit": "GN iterations/s", "cores": nthr, "kind": "port", "cpu_model": cpu_model_name(),
                             "sample": "%d %s, %d threads" % (max(args.cpu_steps, 10 * nthr), sample, nthr),
                             "single_thread": {"value": round(one, 3), "cores": 1, "sample": "%d %s, 1 thread" % (args.cpu_steps, sample)}}
+
+    # ================================================================== the headline workload as a BATCH of independent frames
+    # (dartk_optimize_pose_batch: Optimizer::optimizePose per frame, every launch covers a chunk of 64 frames; what each GPU runs
+    # when a recorded sequence is sharded by frame index) -- the form in which this workload can fill the chip
+    pose_batch = None
+    if not args.no_pose_batch:
+        pf_idx = sharding.shard_indices(args.pose_frames, rank, world)
+        nPF = len(pf_idx)
+        tT, tj, iT, ij = configs.tracking_frames(sc, args.pose_frames)
+        pv, pn = [], []
+        for f in pf_idx:
+            dm.set_pose(tT[f], tj[f])
+            _, v_, n_ = synthetic_observation([dm], sc.width, sc.height, sc.fl, sc.pp)
+            pv.append(v_); pn.append(n_)
+        pvert, pnorm = torch.stack(pv).contiguous(), torch.stack(pn).contiguous()
+        del pv, pn
+        iT_d, ij_d = torch.from_numpy(iT[pf_idx]).to(dev), torch.from_numpy(ij[pf_idx]).to(dev)
+
+        def pstep(debug=False):
+            T_ = iT_d.clone(); j_ = ij_d.clone()
+            opt.optimizePoseBatch(dm, pvert, pnorm, T_, j_, sc.opts, debug=debug)
+            return T_, j_
+
+        pstep()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.pose_steps):
+            T_o, j_o = pstep()
+        barrier()
+        p_elapsed = max_over_ranks(time.perf_counter() - t0)
+        rec_ = torch.cat([T_o, j_o], dim=1)
+        sharding.gather_candidates(args.pose_frames, rank, world, torch.zeros(nPF, device=dev), rec_)      # the poses: the leg's only exchange
+        p_roof = None
+        if rank == 0:
+            p_launch_us, p_step_us, p_launches = prof_collect(lib(), fptr, iptr, check, pstep, 1)
+            n_c = min(nPF, 8)
+
+            def psample(debug=False):
+                T_ = iT_d[:n_c].clone(); j_ = ij_d[:n_c].clone()
+                opt.optimizePoseBatch(dm, pvert[:n_c], pnorm[:n_c], T_, j_, sc.opts, debug=debug)
+                torch.cuda.synchronize()
+            pcnt = count_lookups(psample)
+            psample(debug=True)
+            pinfo = opt.iter_info.cpu().numpy()          # [n_c, iters, 8]
+            per_fi = 1.0 / (n_c * iters)
+            Pp = opt.pred_width * opt.pred_height
+            Sp = 22 + 22 * 23 // 2 + 1
+            Vp = float((pvert[:n_c, :, :, 3] > 0).sum().item()) / n_c
+            recs = pcnt[0] * per_fi
+            lkp = {"fused_obs2mod_kernel": (pcnt[1] + pcnt[2]) * per_fi, "raycast_trace_kernel": pcnt[4] * per_fi, "ne_mod2obs_kernel": pcnt[5] * per_fi}
+            # bytes per frame and iteration: the single-frame leg's formulas with the lookups this batch performed
+            bp = {"fused_obs2mod_kernel": 20.0 * Vp + 32.0 * lkp["fused_obs2mod_kernel"] + 16.0 * pcnt[2] / 6 * per_fi + 4.0 * Sp * ((Vp + 127) // 128),
+                  "raycast_trace_kernel": 32.0 * lkp["raycast_trace_kernel"] + float(TRACE_BYTES_PER_PAIR) * recs,
+                  "ne_mod2obs_kernel": float(TRACE_BYTES_PER_PAIR) * recs + 32.0 * Pp + 32.0 * lkp["ne_mod2obs_kernel"] + 4.0 * Sp * min((Pp + 127) // 128, 1024),
+                  "gn_reduce_kernel": 4.0 * Sp * (min((Pp + 127) // 128, 1024) + (Vp + 127) // 128) + 8.0 * Sp,
+                  "gn_solve_single_kernel": 4.0 * 2 * Sp + 96.0 * 17 * 2}
+            ents = {}
+            for k in bp:
+                if k in p_launch_us:
+                    n_l = p_launches[k]
+                    ents[k] = roofline_entry(k, bp[k] * nPF * iters / n_l, lkp.get(k, 0.0) * nPF * iters / n_l, p_launch_us, batch=True,
+                                             traffic_table=PMC_TRAFFIC_POSE_BATCH, rocprof_table=ROCPROF_POSE_BATCH)
+            if ents:
+                dom = max(ents, key=lambda k: p_step_us.get(k, 0.0))
+                p_roof = dict(ents[dom])
+                it_b = sum(bp[k] for k in ents) * nPF * iters
+                chain = [k for k in ("raycast_trace_kernel", "ne_mod2obs_kernel", "fused_obs2mod_kernel", "gn_reduce_kernel", "gn_solve_single_kernel") if k in p_launches]
+                p_roof.update({
+                    "per_step_us": per_step_from_rocprof(p_launches, True, chain, p_elapsed / args.pose_steps, ROCPROF_POSE_BATCH),
+                    "per_step_us_events": {k: round(v, 2) for k, v in p_step_us.items()},
+                    "launches_per_step": {k: round(v, 2) for k, v in p_launches.items()},
+                    "per_kernel": ents,
+                    "whole_step": {"algorithmic_bytes": round(it_b), "achieved_GBs": round(it_b / (p_elapsed / args.pose_steps) / 1e9, 2),
+                                   "frac": round(it_b / (p_elapsed / args.pose_steps) / 1e9 / HBM_PEAK_GBS, 5)},
+                    "counts_per_frame_and_iteration": {"valid_pixels": Vp, "associated": float(pinfo[:, :, 3].sum()) * per_fi,
+                                                       "predicted": float(pinfo[:, :, 4].sum()) * per_fi, "trace_records": recs,
+                                                       "lookups_performed": lkp, "sample_frames": n_c},
+                    "note": "one stream, five launches per iteration and chunk of 64 frames (trace, replay + mod->obs, obs->mod, reduce, "
+                            "solve); the step also holds the per-call work (pose import / export, valid-pixel lists, observation-SDF builds)"})
+            pose_batch = {"metric": "single-model tracking, batch of independent frames (dartk_optimize_pose_batch)", "unit": "GN iterations/s",
+                          "value": round(args.pose_frames * args.pose_steps * iters / p_elapsed, 2),
+                          "frames_per_s": round(args.pose_frames * args.pose_steps / p_elapsed, 2), "scaling": "strong",
+                          "n_frames": args.pose_frames, "frames_per_gpu": nPF, "steps": args.pose_steps,
+                          "ms_per_step": round(1000.0 * p_elapsed / args.pose_steps, 3), "iterations_per_step": iters, "dtype": "f32",
+                          "data": "synthetic", "roofline": p_roof,
+                          "cpu_baseline": "the headline leg's: the same per-frame workload (cpu_baseline above)",
+                          "config": {"workload": "BASELINE configs[1] per frame (Allegro 22-DOF, 640x480, prediction 320x240, 64^3 obs SDF, obs->mod + "
+                                                 "mod->obs, %d GN iterations), %d frames with their own true and start poses, sharded by index over "
+                                                 "%d GPU(s), one all-gather of the poses; every frame equals the single call bit for bit "
+                                                 "(tests/test_gpu_pose_batch.py)" % (iters, args.pose_frames, world)}}
+        del pvert, pnorm
+        torch.cuda.empty_cache()
 
     # ================================================================== BASELINE config 4: batched ContactGrasp refinement
     grasps = None
@@ -730,7 +828,7 @@ def main():
                                    "prediction 320x240, 64^3 obs SDF, obs->mod + mod->obs, %d GN iterations per optimizePose call, "
                                    "normThreshold %.1f; one frame per GPU" % (iters, sc.opts.normThreshold),
                        "iterations_per_step": iters, "frames_per_gpu": 1, "parallelism": "independent frames, 1 per GPU"},
-            "value_default_gate": value_default_gate, "repeats": repeats, "roofline": roofline, "cpu_baseline": cpu_baseline, "batched_grasps": grasps, "multi_model_tracking": multi,
+            "value_default_gate": value_default_gate, "repeats": repeats, "roofline": roofline, "cpu_baseline": cpu_baseline, "tracking_batch": pose_batch, "batched_grasps": grasps, "multi_model_tracking": multi,
         }
         print(json.dumps(line, default=float))
     if distributed:

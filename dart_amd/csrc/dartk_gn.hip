@@ -192,6 +192,8 @@ fused_obs2mod_kernel(FusedObs2ModArgs fa, ModelView m_in, FrameBatch fb) {
     fa.validIdx += f * fb.pts; fa.nValidPtr += f;
     fa.count += f * fb.counts;
     fa.slabs += f * gridDim.x * sys_size(6 + m.nJoints);
+    // (one workgroup per tile in a batch too: a grid capped below the tile count, each workgroup walking several tiles, was measured
+    // slower at every cap -- 220 us against 160 us per launch of 64 frames of 640x480, caps from 96 to 2400)
     fused_obs2mod_tile<PPT>(blockIdx.x, fa, m, lds);
 }
 
@@ -813,6 +815,7 @@ static int optimize_pose_chunk(Model *mod, int nf, const float *d_vert, const fl
     const size_t o_tgc = take(sizeof(float) * 12 * nf);
     const size_t o_sys = take(sizeof(float) * (size_t)sysStride * nf);
     const size_t o_cnt = take(sizeof(int) * 2 * (size_t)nf);
+    const size_t o_rtab = take(sizeof(float) * (28 * (size_t)m0.nSdfs + 1) * nf * (useB ? 1 : 0));
     void *base = nullptr;
     rc = batch_scratch(total, &base);
     if (rc) return rc;
@@ -856,7 +859,7 @@ static int optimize_pose_chunk(Model *mod, int nf, const float *d_vert, const fl
     for (int it = 0; it < o->numIterations; ++it) {
         if (useB) {
             rc = gn_launch_raycast_ne_mod2obs(o->predFl[0], o->predFl[1], (float)(o->predWidth / 2), (float)(o->predHeight / 2), o->predWidth,
-                                              o->predHeight, 0, m, d_pred, d_T_gc, slabsB, nBlocksB, cntB, st, nullptr, false, nullptr);
+                                              o->predHeight, 0, m, d_pred, d_T_gc, slabsB, nBlocksB, cntB, st, nullptr, false, nullptr, at(o_rtab));
             if (rc) return rc;
         }
         if (useA) {

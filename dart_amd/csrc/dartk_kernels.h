@@ -69,7 +69,8 @@ int gn_obs_sdf_build(const float *d_vert, int width, int height, Model *mod, flo
 int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                                  float *d_prediction, const float *d_T_gc, float *slabs, int nBlocks, int *d_num, hipStream_t st,
                                  hipEvent_t beforeNe = nullptr, bool traceDone = false /* the caller has launched the trace on st */,
-                                 const float *d_tables = nullptr /* the replay tables of this pose, if an earlier kernel left them */);
+                                 const float *d_tables = nullptr /* the replay tables of this pose, if an earlier kernel left them */,
+                                 float *d_batchTables = nullptr /* a batch: [frames][28 nSdfs + 1] floats this call fills and uses */);
 int gn_launch_ne_mod2obs(const float *d_pred, int width, int height, const ModelView &m, const float *d_T_gc,
                          float *slabs, int nBlocks, int *d_num, hipStream_t st);
 int gn_launch_ne_self(const float *d_sites, int nSites, const ModelView &m, const int *d_pot, float *slabs, int nBlocks,

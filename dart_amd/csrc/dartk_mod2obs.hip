@@ -448,7 +448,17 @@ struct ReplayArgs {            // REPLAY variant: the prediction is formed in th
     // optional: this pose's [per-SDF ray transforms (24 nSdfs floats) | tile rectangles (4 nSdfs + 1 ints)] as an earlier kernel of
     // the iteration left them (replay_tables_to_global): one coalesced load instead of recomputing them in every workgroup
     const float *tables;
+    int tablesStride;          // floats between two frames' tables (a batch), else 0
 };
+
+// a batch's replay tables: one workgroup per frame leaves what replay_tables_to_global computes for the frame's pose
+__global__ void __launch_bounds__(NE_BLOCK)
+replay_tables_kernel(ModelView m_in, float flx, float fly, float ppx, float ppy, int width, int height, float *__restrict__ tables, int stride) {
+    extern __shared__ float lds[];
+    ModelView m = m_in;
+    select_frame(m, blockIdx.x);
+    replay_tables_to_global(m, flx, fly, ppx, ppy, width, height, lds, tables + (size_t)blockIdx.x * stride);
+}
 
 template <int PPT, int RED, bool TRUNC, bool REPLAY = false>
 __global__ void __launch_bounds__(NE_BLOCK)
@@ -469,6 +479,7 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
     if (REPLAY) {       // the frame's slice of the trace buffer (fb.trace floats apart) and of the prediction maps
         ra.trace += (size_t)blockIdx.y * (fb.trace / 2);
         ra.predOut += (size_t)blockIdx.y * fb.pred;
+        if (ra.tables) ra.tables += (size_t)blockIdx.y * ra.tablesStride;
     }
     // hit-list form (batches): `pred` holds the frame's hits back to back, nItems[frame] of them (raycast_replay_multi_rows_kernel)
     if (nItems) nPix = nItems[(size_t)blockIdx.y * fb.counts];
@@ -762,7 +773,7 @@ int gn_launch_raycast_replay_at(float flx, float fly, float ppx, float ppy, int 
 // traces (writing the prediction for the caller) and goes on with the pixel -- one launch less on the critical path
 int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,
                                  float *d_prediction, const float *d_T_gc, float *slabs, int nBlocks, int *d_num, hipStream_t st,
-                                 hipEvent_t beforeNe, bool traceDone, const float *d_tables) {
+                                 hipEvent_t beforeNe, bool traceDone, const float *d_tables, float *d_batchTables) {
     // beforeNe: an event the normal-equation kernel (the first reader of the obs SDF and of T_gc) waits for; the
     // ray-cast needs neither and starts at once
     if (m.nSdfs > NE_BLOCK) {
@@ -784,10 +795,18 @@ int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int
     const int d = 6 + m.nJoints, S = sys_size(d), nPix = width * height;
     const size_t ldsBytes = ne_mod2obs_lds_bytes(m, d, 0) + sizeof(float) * (28 * (size_t)m.nSdfs + 1);
     DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
-    const ReplayArgs ra = {flx, fly, ppx, ppy, width, modelNum, (const float2 *)ws->rayBuf, (float4 *)d_prediction, d_tables};
-    // a batch (dartk_optimize_pose_batch): grid.y = frame, T_gc in the per-frame table, no shared replay tables
+    // a batch (dartk_optimize_pose_batch): grid.y = frame, T_gc in the per-frame table, the replay tables of every frame's pose
+    // written once here instead of being rebuilt by each of the frame's hundreds of workgroups
     const FrameBatch fb = cur_batch();
-    DARTK_REQUIRE(fb.n == 1 || !d_tables, "replay tables are per pose: a batch rebuilds them in the kernel");
+    DARTK_REQUIRE(fb.n == 1 || !d_tables, "replay tables are per pose: a batch passes d_batchTables");
+    const int tabStride = 28 * m.nSdfs + 1;
+    if (fb.n > 1 && d_batchTables) {
+        hipLaunchKernelGGL(replay_tables_kernel, dim3(fb.n), dim3(NE_BLOCK), sizeof(float) * tabStride, st, m, flx, fly, ppx, ppy, width, height,
+                           d_batchTables, tabStride);
+        d_tables = d_batchTables;
+    }
+    const ReplayArgs ra = {flx, fly, ppx, ppy, width, modelNum, (const float2 *)ws->rayBuf, (float4 *)d_prediction, d_tables,
+                           fb.n > 1 ? tabStride : 0};
     const int tgcStride = fb.n > 1 ? fb.tab : 0;
     ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
 #define DARTK_LAUNCH_RM2O(PPT_)                                                                                 \

@@ -13,4 +13,7 @@ python3 tools/kernel_durations.py $O/stats profiles/kernel_durations.json > /dev
 python3 tools/pmc_summary.py "$(one fetch counter_collection)" "$(one write counter_collection)" profiles/pmc_traffic.json > profiles/${TAG}_pmc_hbm_traffic.txt
 python3 tools/pmc_summary.py --largest "$(one fetch5 counter_collection)" "$(one write5 counter_collection)" profiles/pmc_traffic_batch.json > profiles/${TAG}_pmc_hbm_traffic_batch.txt
 python3 tools/l2_summary.py "$(one l2 counter_collection)" profiles/l2_hit_rate.json > profiles/${TAG}_pmc_l2_hit_rate.txt
+python3 tools/prof_summary.py "$(one statsP kernel_trace)" > profiles/${TAG}_kernel_stats_pose_batch.txt
+python3 tools/kernel_durations.py $O/statsP profiles/kernel_durations_pose_batch.json > /dev/null
+python3 tools/pmc_summary.py --largest "$(one fetchP counter_collection)" "$(one writeP counter_collection)" profiles/pmc_traffic_pose_batch.json > profiles/${TAG}_pmc_hbm_traffic_pose_batch.txt
 echo "profiles/${TAG}_* written"

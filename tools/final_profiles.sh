@@ -5,7 +5,9 @@
 #   (256 frames per launch), and a per-launch mean over both says nothing about either; the batch gets two passes of its own.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-CMD="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --grasp-steps 1 --repeats 0 --multi-steps 1"
+CMD="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --grasp-steps 1 --repeats 0 --multi-steps 1 --no-pose-batch"
+# the single-model frame batch alone (its launches share kernel names with the other legs'): a kernel trace and two PMC passes of its own
+CMDP="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --repeats 0 --no-tracking --no-grasps --no-multi-model --pose-steps 1"
 O=gpurun_out/final
 mkdir -p $O
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $CMD > $O/stats.log 2>&1
@@ -16,4 +18,7 @@ timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -
 timeout -s KILL 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $O/l2 -- $CMD1 > $O/l2.log 2>&1
 timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch5 -- $CMD5 > $O/fetch5.log 2>&1
 timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write5 -- $CMD5 > $O/write5.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/statsP -- $CMDP > $O/statsP.log 2>&1
+timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetchP -- $CMDP > $O/fetchP.log 2>&1
+timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/writeP -- $CMDP > $O/writeP.log 2>&1
 echo profiles done
