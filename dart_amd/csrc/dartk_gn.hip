@@ -32,6 +32,7 @@ int prof_push(int cls, hipStream_t st) {
     g_prof.push_back(e);
     return (int)g_prof.size() - 1;
 }
+bool prof_enabled() { return g_prof_on; }
 void prof_pop(int idx, hipStream_t st) { (void)hipEventRecord(g_prof[idx].b, st); }
 
 // -----------------------------------------------------------------------------------------------------

@@ -99,6 +99,7 @@ int gn_ne_inter_any(int red, const float *d_sites, int nSites, int fullDims, int
 // optional per-kernel-class timing with HIP events on the launch stream (dartk_profile_begin / _end)
 int prof_push(int cls, hipStream_t st);       // returns an event-pair index or -1 when profiling is off
 void prof_pop(int idx, hipStream_t st);
+bool prof_enabled();
 struct ProfScope {
     hipStream_t st; int idx;
     ProfScope(int cls, hipStream_t s) : st(s), idx(prof_push(cls, s)) {}

@@ -49,6 +49,7 @@ struct MultiSolveArgs {
     // the association / prediction counters of a frame (fb.counts ints each): cleared here for the next iteration's kernels
     // instead of by two memset launches per iteration (null: the term is off)
     int *zeroA, *zeroB;
+    int *itCounter;         // every solve leaves its iteration number + 1 here (read by a launch with iteration == -3)
 };
 
 // projection of the reduced articulation in ra[] (LDS) to the full joint vector (pose.cpp:66-73, 91-97) and forward
@@ -182,12 +183,15 @@ __device__ __noinline__ void multi_eval_contact_prior(const MultiSolveArgs &a, i
     }
 }
 
+// iteration: >= 0 the Gauss-Newton iteration; -1 / -2 import / export of a batch's poses; -3 the iteration whose number the
+// previous solve left in *a.itCounter (the replayed launches of a captured iteration all carry the same argument)
 __global__ void __launch_bounds__(64)
 multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration) {
     extern __shared__ float lds[];
     const MultiSolveArgs &a = *ap;
     const int lane = threadIdx.x;
     const int frame = blockIdx.x;                   // frame of a batch (0 otherwise)
+    if (iteration == -3) iteration = *a.itCounter;
     const size_t so = (size_t)frame * a.fb.sys, co = (size_t)frame * a.fb.counts;
     const int D = a.D;
     const int ldU = (D + 1) | 1;
@@ -328,6 +332,7 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration) {
         if (a.zeroA) a.zeroA[co + lane] = 0;
         if (a.zeroB) a.zeroB[co + lane] = 0;
     }
+    if (lane == 0 && frame == 0 && a.itCounter) *a.itCounter = iteration + 1;
 }
 
 // per-device buffers of the loop (argument block, per-term systems, small tables)
@@ -402,7 +407,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     // one allocation: [args | countA | countB | shared tables | per-frame tables | per-frame systems] and, for a batch,
     // [poses | observation SDFs | distance-transform scratch | prediction maps | association lists]
     const size_t argBytes = (sizeof(MultiSolveArgs) + 255) / 256 * 256;
-    const size_t cntInts = 2 * (size_t)DARTK_MAX_MODELS * nFrames;
+    const size_t cntInts = 2 * (size_t)DARTK_MAX_MODELS * nFrames + 4;      // + the iteration counter
     size_t floatsSmall = tableFloats + (size_t)nFrames * (tabStride + sysFloats);
     size_t total = argBytes + sizeof(int) * cntInts + sizeof(float) * floatsSmall + 1024;
     size_t o_pose = 0, o_obs = 0, o_tmp = 0, o_pred = 0, o_pts = 0;
@@ -420,7 +425,8 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     MultiSolveArgs *d_args = reinterpret_cast<MultiSolveArgs *>(base);
     int *d_countA = reinterpret_cast<int *>((char *)base + argBytes);
     int *d_countB = d_countA + (size_t)DARTK_MAX_MODELS * nFrames;
-    float *fl = reinterpret_cast<float *>(d_countB + (size_t)DARTK_MAX_MODELS * nFrames);
+    int *d_itCounter = d_countB + (size_t)DARTK_MAX_MODELS * nFrames;
+    float *fl = reinterpret_cast<float *>(d_itCounter + 4);
     if (batch) {
         for (int m = 0; m < n; ++m) {       // model m's frame records lie back to back: [frame][T_mc|T_cm|T_mf|T_fm|joints]
             views[m] = *mods[m];
@@ -491,6 +497,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     h.iterInfo = d_iterInfo; h.firstSystem = d_firstSystem;
     h.priors = d_priors; h.nPriors = nPriors;
     h.zeroA = useA ? d_countA : nullptr; h.zeroB = useB ? d_countB : nullptr;
+    h.itCounter = d_itCounter;
     h.fb = fb; h.redStride = batch ? redTotal : 0; h.infoStride = batch ? (size_t)o->numIterations * n * 8 : 0; h.T_mcs = d_T_mcs;
     {   // argument block and tables leave through a pinned slot: the call does not wait for the stream
         ArgSlot slot;
@@ -580,7 +587,8 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     } joinGuard{ws, st, stA, stC, false};
     // both counter arrays start at zero; every solve launch leaves them cleared for the next iteration
     DARTK_HIP(hipMemsetAsync(d_countA, 0, 2 * (size_t)DARTK_MAX_MODELS * nFrames * sizeof(int), st));
-    for (int it = 0; it < o->numIterations; ++it) {
+    auto run_iteration = [&](int it, int solveArg) -> int {
+        int rc = DARTK_OK;
         if (par) {      // the poses of this iteration are final on `st`
             DARTK_HIP(hipEventRecord(ws->evFork, st));
             DARTK_HIP(hipStreamWaitEvent(stA, ws->evFork, 0));
@@ -660,7 +668,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         if (ws->deferReduce) { rc = flush_reduce_jobs(ws, st); if (rc) return rc; }
         {
             ProfScope ps(DARTK_PROF_SOLVE, st);
-            hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64), ldsSolve, st, d_args, it);
+            hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64), ldsSolve, st, d_args, solveArg);
         }
         DARTK_HIP(hipGetLastError());
         if (deferLater && it == 0) {
@@ -671,6 +679,15 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
             if (rc) return rc;
             ws->deferReduce = true;
         }
+        return DARTK_OK;
+    };
+    // (Measured and left out: capturing iteration 1 as a HIP graph -- three streams, forks and joins included -- and launching the
+    // graph for the remaining iterations. On ROCm 7.2 hipGraphLaunch of the 15-node graph costs the host 70 us, 4.7 us per node, no
+    // less than the ~22 direct calls it replaces: 4.1-4.4 k GN it/s against 5.5 k. The solve kernel's iteration == -3 form, which reads
+    // the iteration number from device memory, remains from that experiment.)
+    for (int it = 0; it < o->numIterations; ++it) {
+        rc = run_iteration(it, it);
+        if (rc) return rc;
     }
     ws->deferReduce = false;
     if (batch) {                // export the poses

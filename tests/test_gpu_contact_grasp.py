@@ -87,7 +87,7 @@ def test_get_error_matches_oracle(gpu):
 def segmented_grasp(name, sc, tr, T1, j1, iters):
     """tests/trajectory.py for one grasp candidate (T1 [2,12], j1 [nJ]): GPU prefixes (batch of one) vs the oracle restarted
     from the GPU's poses at every decision flip. Returns (segments, gpu end pose, gpu energy, oracle energy of the last segment)."""
-    from trajectory import segmented_parity
+    from trajectory import parts, segmented_parity
     oms = [O.OModel(sc.hand, 0), O.OModel(sc.obj, 1)]
     clouds = [c.cpu().numpy() for c in tr.clouds]
     pots = [p.cpu().numpy() for p in tr.potentials]
@@ -114,9 +114,17 @@ def segmented_grasp(name, sc, tr, T1, j1, iters):
     def pose_err(a, b):
         dt, dr = pose_diff(a[0], b[0])
         dto, dro = pose_diff(a[1], b[1])
-        return max(dt, dr, dto, dro, float(np.abs(a[2] - b[2]).max()))
+        return parts(translation_m=[dt, dto], rotation_rad=[dr, dro], joints_rad=[np.abs(a[2] - b[2]).max()])
 
-    segs = segmented_parity(name, iters, gpu_prefix, oracle_from, decisions_equal, pose_err, bar=1e-3)
+    def near_ties(gpose, opose, k):
+        import near_ties as NT
+        dims = [oms[0].dims, oms[1].dims]
+        zero = np.zeros(0, dtype=F)
+        recs = NT.prior_near_ties(oms, sc.priors, ([gpose[0], gpose[1]], [gpose[2], zero]), ([opose[0], opose[1]], [opose[2], zero]),
+                                  dims, [0, dims[0]])
+        return recs
+
+    segs = segmented_parity(name, iters, gpu_prefix, oracle_from, decisions_equal, pose_err, bar=1e-3, near_ties=near_ties)
     tr.getOptions().numIterations = iters
     return segs, poses[iters], energies[iters], energies[("oracle", iters)]
 

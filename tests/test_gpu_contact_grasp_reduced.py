@@ -81,7 +81,7 @@ def oracle_args(sc, tr):
 
 @pytest.mark.parametrize("kind", ["linear", "map"])
 def test_reduced_refinement_matches_oracle(gpu, kind):
-    from trajectory import segmented_parity
+    from trajectory import parts, segmented_parity
     sc, tr, priors, T, J = barrett_scene(kind)
     oms, clouds, pots = oracle_args(sc, tr)
     dims = [tr.reduced_dims(0), tr.reduced_dims(1)]
@@ -124,7 +124,7 @@ def test_reduced_refinement_matches_oracle(gpu, kind):
             def pose_err(a, b):
                 dt, dr = pose_diff(a[0], b[0])
                 dto, dro = pose_diff(a[1], b[1])
-                return max(dt, dr, dto, dro, float(np.abs(a[2] - b[2]).max()))
+                return parts(translation_m=[dt, dto], rotation_rad=[dr, dro], joints_rad=[np.abs(a[2] - b[2]).max()])
 
             segmented_parity("Barrett ContactGrasp (%s reduction) candidate %d" % (kind, c), iters, gpu_prefix, oracle_from, decisions_equal, pose_err, bar=1e-3)
             end, _ = gpu_prefix(iters)

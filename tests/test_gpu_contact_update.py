@@ -28,7 +28,7 @@ def noobs_tracker(sc, priors, max_batch=4):
 
 
 def test_noobs_contact_points_move_as_in_the_oracle(gpu):
-    from trajectory import segmented_parity
+    from trajectory import parts, segmented_parity
     sc, oms, priors = scene(n_update=4)
     upd = [k for k, p in enumerate(priors) if p.update_contact_point]
     assert len(upd) >= 3
@@ -78,7 +78,8 @@ def test_noobs_contact_points_move_as_in_the_oracle(gpu):
         return bool(abs(g[1] - o_[1]) <= 5e-2 + 2e-4 * abs(o_[1]) and abs(g[0] - o_[0]) <= 1e-4 * abs(o_[0]) + 1e-7)
 
     def pose_err(a, b):
-        return max(*pose_diff(a[0], b[0]), *pose_diff(a[1], b[1]), float(np.abs(a[2] - b[2]).max()), float(np.abs(a[3] - b[3]).max()))
+        (dt, dr), (dto, dro) = pose_diff(a[0], b[0]), pose_diff(a[1], b[1])
+        return parts(translation_m=[dt, dto], rotation_rad=[dr, dro], joints_rad=[np.abs(a[2] - b[2]).max()], other=[np.abs(a[3] - b[3]).max()])
 
     segmented_parity("NoObs with moving contact points", 10, gpu_prefix, oracle_from, decisions_equal, pose_err, bar=1e-3)
 

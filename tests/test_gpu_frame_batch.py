@@ -93,7 +93,7 @@ def test_frame_result_does_not_depend_on_the_batch(gpu):
 
 def test_batch_frame_against_the_oracle(gpu):
     """One frame of a batch against the CPU oracle directly (segment by segment, tests/trajectory.py)."""
-    from trajectory import segmented_parity
+    from trajectory import parts, segmented_parity
     ks = (2, 5, 7)
     iters = 4
     tr, scs, vert, norm, T0, a0 = frames(320, 180, ks, iters)
@@ -112,11 +112,9 @@ def test_batch_frame_against_the_oracle(gpu):
         return [(oT[m], oa[m]) for m in range(2)], oinfo
 
     def pose_err(a, b):
-        e = 0.0
-        for m in range(2):
-            dt, dr = pose_diff(a[m][0], b[m][0])
-            e = max(e, dt, dr, float(np.abs(a[m][1] - b[m][1]).max()) if len(b[m][1]) else 0.0)
-        return e
+        d = [pose_diff(a[m][0], b[m][0]) for m in range(2)]
+        return parts(translation_m=[x[0] for x in d], rotation_rad=[x[1] for x in d],
+                     joints_rad=[np.abs(a[m][1] - b[m][1]).max() for m in range(2) if len(b[m][1])])
 
     segmented_parity("C5 frame %d inside a batch of %d" % (ks[i], len(ks)), iters, gpu_prefix, oracle_from,
                      lambda g, o: bool(np.array_equal(g[:, 3:5], o[:, 3:5])), pose_err, bar=1e-3)

@@ -95,7 +95,7 @@ def test_moving_the_seam_changes_nothing(batch, chunk):
 
 
 def test_frame_of_the_second_chunk_against_the_oracle(batch):
-    from trajectory import segmented_parity
+    from trajectory import parts, segmented_parity
     tr, sc, vert, norm, T0, a0 = batch
     i = 70
     v_np, n_np = vert[i].cpu().numpy(), norm[i].cpu().numpy()
@@ -112,11 +112,9 @@ def test_frame_of_the_second_chunk_against_the_oracle(batch):
         return [(oT[m], oa[m]) for m in range(2)], oinfo
 
     def pose_err(a, b):
-        e = 0.0
-        for m in range(2):
-            dt, dr = pose_diff(a[m][0], b[m][0])
-            e = max(e, dt, dr, float(np.abs(a[m][1] - b[m][1]).max()) if len(b[m][1]) else 0.0)
-        return e
+        d = [pose_diff(a[m][0], b[m][0]) for m in range(2)]
+        return parts(translation_m=[x[0] for x in d], rotation_rad=[x[1] for x in d],
+                     joints_rad=[np.abs(a[m][1] - b[m][1]).max() for m in range(2) if len(b[m][1])])
 
     segmented_parity("C5 frame %d (second chunk) of a batch of %d" % (i, N_FRAMES), ITERS, gpu_prefix, oracle_from,
                      lambda g, o: bool(np.array_equal(g[:, 3:5], o[:, 3:5])), pose_err, bar=1e-3)

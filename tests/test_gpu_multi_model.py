@@ -39,7 +39,7 @@ def run(width, height, iters, frame=0, device_loop=False):
 def segmented(sc, tr, vert, norm, iters, device_loop):
     """tests/trajectory.py for Optimizer::optimizePoses: every segment between count flips held to 1e-3, the oracle restarted
     from the GPU's poses (observation SDFs kept at the run's start poses)."""
-    from trajectory import segmented_parity
+    from trajectory import parts, segmented_parity
     v_np, n_np = vert.cpu().numpy(), norm.cpu().numpy()
     init_T = [T for T, _ in sc.init]
 
@@ -62,12 +62,9 @@ def segmented(sc, tr, vert, norm, iters, device_loop):
         return bool(np.array_equal(g[:, 3:5], o[:, 3:5]))
 
     def pose_err(a, b):
-        e = 0.0
-        for m in range(2):
-            dt, dr = pose_diff(a[m][0], b[m][0])
-            da = float(np.abs(a[m][1] - b[m][1]).max()) if len(b[m][1]) else 0.0
-            e = max(e, dt, dr, da)
-        return e
+        d = [pose_diff(a[m][0], b[m][0]) for m in range(2)]
+        return parts(translation_m=[x[0] for x in d], rotation_rad=[x[1] for x in d],
+                     joints_rad=[np.abs(a[m][1] - b[m][1]).max() for m in range(2) if len(b[m][1])])
 
     name = "C5 %dx%d %s loop" % (sc.width, sc.height, "device" if device_loop else "host-driven")
     segs = segmented_parity(name, iters, gpu_prefix, oracle_from, decisions_equal, pose_err, bar=1e-3)

@@ -46,7 +46,7 @@ def pose_diff(Ta, Tb):
 def segmented_pose_parity(sc0, cfg, size, gpu, iters, lam_m2o=1.0):
     """tests/trajectory.py for Optimizer::optimizePose: GPU prefixes from the common start vs the oracle restarted from the
     GPU's pose at every decision flip (observation SDF kept at the run's start pose, as the original call has it)."""
-    from trajectory import segmented_parity
+    from trajectory import parts, segmented_parity
     sc = cfg(*size)
     m = sc.host_model
     om = O.OModel(m, 0, sc.obs_layout)
@@ -76,9 +76,16 @@ def segmented_pose_parity(sc0, cfg, size, gpu, iters, lam_m2o=1.0):
 
     def pose_err(a, b):
         dt, dr = pose_diff(a[0], b[0])
-        return max(dt, dr, float(np.abs(a[1] - b[1]).max()) if len(a[1]) else 0.0)
+        return parts(translation_m=[dt], rotation_rad=[dr], joints_rad=[np.abs(a[1] - b[1]).max()] if len(a[1]) else [])
 
-    return segmented_parity(sc.name, iters, gpu_prefix, oracle_from, decisions_equal, pose_err, bar=1e-3)
+    def near_ties(gpose, opose, k):
+        import near_ties as NT
+        recs = NT.association_near_ties(om, v_np, n_np, sc.opts, gpose, opose)
+        NT.assert_explained(recs, "%s iteration %d" % (sc.name, k))
+        return recs
+
+    return segmented_parity("%s %dx%d" % (sc.name, sc.width, sc.height), iters, gpu_prefix, oracle_from, decisions_equal, pose_err, bar=1e-3,
+                            near_ties=near_ties)
 
 
 @pytest.mark.parametrize("cfg,size", [(configs.config1, (320, 240)), (configs.config2, (320, 240)), (configs.config2_left_hand, (320, 240))])
@@ -128,13 +135,52 @@ def test_optimize_pose_obs_to_mod_only_and_zero_iterations(gpu):
     assert np.array_equal(g_T, configs.config2(160, 120).init_T_mc)
 
 
+def test_association_flips_under_a_small_pose_change_are_near_ties(gpu):
+    """The documentation north_star asks for, on a case that HAS flips: the same 640x480 frame associated at a pose and at that
+    pose moved by 2e-5 m and 1e-5 rad (two summation orders differ by 1e-7 and flip nothing here; the larger step makes the list
+    non-empty). GPU and oracle agree bit for bit at each pose, so the
+    pixels that flip are the same on both; each is listed with its margin and must have its threshold between the two poses'
+    values. The list goes to the parity records (tests/golden/parity_records/)."""
+    import near_ties as NT
+    from trajectory import store_record
+    sc = configs.config2()
+    m = sc.host_model
+    om = O.OModel(m, 0, sc.obs_layout)
+    dm = D.DeviceModel(m, model_id=0, obs_layout=sc.obs_layout)
+    dm.set_pose(sc.true_T_mc, sc.true_joints)
+    _, vert, norm = synthetic_observation([dm], sc.width, sc.height, sc.fl, sc.pp)
+    v_np, n_np = vert.cpu().numpy(), norm.cpu().numpy()
+    sc.opts.normThreshold = -0.1            # the reference's default gate: both criteria can flip
+    sc.opts.distThreshold = [0.004]         # a threshold that cuts through the start pose's residuals (1.5 cm off): many pixels near it
+    pose_a = (sc.init_T_mc.copy(), sc.init_joints.copy())
+    pose_b = (se3.mul(se3.exp(np.array([2e-5, -1e-5, 1.5e-5, 1e-5, 0, -1e-5], dtype=F)), sc.init_T_mc), sc.init_joints.copy())
+    das = []
+    for T, j in (pose_a, pose_b):
+        dm.set_pose(T, j)
+        pts, count, dbg = D.error_and_data_association(vert, norm, dm, dist_threshold=sc.opts.distThreshold[0], norm_threshold=-0.1, debug=True)
+        das.append(dbg["da"].cpu().numpy().reshape(-1).copy())
+    recs = NT.association_near_ties(om, v_np, n_np, sc.opts, pose_a, pose_b)
+    gpu_flips = set(np.nonzero(das[0] != das[1])[0].tolist())
+    assert gpu_flips == {r["pixel"] for r in recs}, "GPU and oracle disagree on which pixels flip"
+    NT.assert_explained(recs, "C2 640x480 association under a 2e-5 m pose change")
+    n_assoc = int((das[0] >= 0).sum())
+    print("association of %d pixels at two poses 2e-5 m apart: %d flip, margins %s" % (n_assoc, len(recs), sorted(r["margin"] for r in recs)[:6]))
+    assert n_assoc > 1000 and 0 < len(recs) < n_assoc // 20
+    store_record("C2 640x480 association near-ties under a 2e-5 m pose change",
+                 {"associated": n_assoc, "flipped": len(recs), "near_ties": recs,
+                  "largest_margin": max([r["margin"] for r in recs], default=0.0)})
+
+
 def test_optimize_pose_full_resolution_c2(gpu):
     """BASELINE config 2 at its full size (640x480, prediction 320x240): size-independent properties + oracle."""
     sc = configs.config2()
     dm, g_T, g_j, g_info, g_first, o_T, o_j, o_info, o_first = run_scene(sc, gpu, iters=5)
     dims = 22
     S = O.sys_len(dims)
-    assert np.array_equal(g_info[:, 3], o_info[:, 3][:len(g_info)]) or abs(g_info[-1, 3] - o_info[-1, 3]) <= 0.002 * o_info[-1, 3]
+    # counts: equal in every iteration, or the run's flips are listed and shown to be near-ties by the segmented comparison below
+    counts_equal = bool(np.array_equal(g_info[:, 3:5], o_info[:len(g_info), 3:5]))
+    segs = segmented_pose_parity(sc, configs.config2, (640, 480), gpu, 5)
+    assert counts_equal == (len(segs) == 1)
     assert rel_err_blocks(g_first[:S], o_first[:S], dims) < 1e-4
     assert rel_err_blocks(g_first[S:2 * S], o_first[S:2 * S], dims) < 1e-4
     dt, dr = pose_diff(g_T, o_T)
