@@ -3,6 +3,7 @@
 #include "dartk_internal.h"
 #include "dartk_reduce.h"
 #include "dartk_kernels.h"
+#include "dartk_ne_bodies.h"
 
 namespace dartk {
 
@@ -12,55 +13,7 @@ __global__ void __launch_bounds__(NE_BLOCK)
 ne_self_intersection_kernel(const float4 *__restrict__ sites, int nSites, ModelView m_in, const int *__restrict__ pot,
                             int redDims, const float *__restrict__ dtheta_dalpha, const int *__restrict__ mapping,
                             float *__restrict__ slabs) {
-    extern __shared__ float lds[];
-    ModelView m = m_in;
-    select_frame(m, blockIdx.y);                    // frame of a batch (0 otherwise)
-    const int fullDims = 6 + m.nJoints;
-    const int d = (RED ? redDims : fullDims) - 6;
-    const int ld = row_len(d, false);
-    float *sT_fm = lds;
-    float *sT_mf = sT_fm + 12 * m.nFrames;
-    const int fullLd = (fullDims - 6) | 1;
-    float *sFull = sT_mf + 12 * m.nFrames;
-    float *rows = sFull + (RED ? NE_BLOCK * fullLd : 0);
-    int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ld);
-    stage_model(m, sT_fm, sT_mf, nullptr);
-    __syncthreads();
-    PairAcc<NE_BLOCK, PPT> acc;
-    acc.init(d, false);
-    const int nTiles = (nSites + NE_BLOCK - 1) / NE_BLOCK;
-    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
-        const int index = tile * NE_BLOCK + threadIdx.x;
-        Collision c; c.hit = false;
-        f3 vm; vm.x = vm.y = vm.z = 0.f;
-        int srcFrame = 0;
-        if (index < nSites) {
-            const float4 v = sites[index];
-            const int srcGrid = (int)roundf(v.w);
-            srcFrame = m.sdfFrame[srcGrid];
-            vm = se3_apply_w(sT_mf + 12 * srcFrame, v.x, v.y, v.z, 1.0f);
-            c = first_collision(m, sT_fm, vm, pot, srcGrid);
-        }
-        int nActive;
-        const int slot = compact_slot<NE_BLOCK>(c.hit, waveCnt, nActive);
-        if (c.hit) {
-            float *row = rows + slot * ld;
-            const SdfDev &s = m.sdfs[c.dstGrid];
-            const int dstFrame = m.sdfFrame[c.dstGrid];
-            const f3 gf = sdf_gradient<CNT_INTER>(m.grids, s, c.vg);
-            const f3 gm = se3_rotate(sT_mf + 12 * dstFrame, gf);
-            float *Jfull = RED ? (sFull + threadIdx.x * fullLd) : row;
-            error_jacobian<true>(Jfull, vm, 1.0f, m.depMask[srcFrame], gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
-            if (RED) reduce_jacobian<RED>(row, Jfull, 0, fullDims, redDims, dtheta_dalpha, mapping);
-            row[d] = c.residual;
-            row[d + 1] = (float)(0.5 * (double)c.residual * (double)c.residual);
-            row[d + 2] = 1.0f;
-        }
-        __syncthreads();
-        if (nActive) acc.accumulate(rows, ld, nActive);
-        __syncthreads();
-    }
-    acc.store(slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * sys_size(d), sys_size(d));
+    ne_self_intersection_body<PPT, RED>(sites, nSites, m_in, pot, redDims, dtheta_dalpha, mapping, slabs, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // INTER-MODEL: source cloud in destination SDFs, full source-pose system (intersection.cu:367-597).
@@ -69,65 +22,7 @@ __global__ void __launch_bounds__(NE_BLOCK)
 ne_intersection_kernel(const float4 *__restrict__ sites, int nSites, ModelView src_in, ModelView dst_in,
                        const float *__restrict__ T_ds_sd /* [24] */, int redDims, const float *__restrict__ dtheta_dalpha,
                        const int *__restrict__ mapping, float *__restrict__ slabs, int tabStride) {
-    extern __shared__ float lds[];
-    ModelView src = src_in, dst = dst_in;
-    select_frame(src, blockIdx.y);                  // frame of a batch (0 otherwise)
-    select_frame(dst, blockIdx.y);
-    T_ds_sd += (size_t)blockIdx.y * tabStride;
-    const int fullDims = 6 + src.nJoints;
-    const int d = RED ? redDims : fullDims;
-    const int ld = row_len(d, false);
-    float *sT_fm = lds;                               // source transforms
-    float *sT_mf = sT_fm + 12 * src.nFrames;
-    float *dT_fm = sT_mf + 12 * src.nFrames;          // destination transforms
-    float *dT_mf = dT_fm + 12 * dst.nFrames;
-    const int fullLd = fullDims | 1;
-    float *sFull = dT_mf + 12 * dst.nFrames;
-    float *rows = sFull + (RED ? NE_BLOCK * fullLd : 0);
-    int *waveCnt = reinterpret_cast<int *>(rows + NE_BLOCK * ld);
-    stage_model(src, sT_fm, sT_mf, nullptr);
-    stage_model(dst, dT_fm, dT_mf, nullptr);
-    float T_ds[12], T_sd[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { T_ds[i] = T_ds_sd[i]; T_sd[i] = T_ds_sd[12 + i]; }
-    __syncthreads();
-    PairAcc<NE_BLOCK, PPT> acc;
-    acc.init(d, false);
-    const int nTiles = (nSites + NE_BLOCK - 1) / NE_BLOCK;
-    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
-        const int index = tile * NE_BLOCK + threadIdx.x;
-        Collision c; c.hit = false;
-        f3 vsm; vsm.x = vsm.y = vsm.z = 0.f;
-        int srcFrame = 0;
-        if (index < nSites) {
-            const float4 v = sites[index];
-            const int srcGrid = (int)roundf(v.w);
-            srcFrame = src.sdfFrame[srcGrid];
-            vsm = se3_apply_w(sT_mf + 12 * srcFrame, v.x, v.y, v.z, 1.0f);
-            const f3 vdm = se3_apply_w(T_ds, vsm.x, vsm.y, vsm.z, 1.0f);
-            c = first_collision(dst, dT_fm, vdm, nullptr, 0);
-        }
-        int nActive;
-        const int slot = compact_slot<NE_BLOCK>(c.hit, waveCnt, nActive);
-        if (c.hit) {
-            float *row = rows + slot * ld;
-            const SdfDev &s = dst.sdfs[c.dstGrid];
-            const int dstFrame = dst.sdfFrame[c.dstGrid];
-            const f3 gf = sdf_gradient<CNT_INTER>(dst.grids, s, c.vg);
-            const f3 gdm = se3_rotate(dT_mf + 12 * dstFrame, gf);
-            const f3 gsm = se3_rotate(T_sd, gdm);
-            float *Jfull = RED ? (sFull + threadIdx.x * fullLd) : row;
-            error_jacobian<false>(Jfull, vsm, 1.0f, src.depMask[srcFrame], gsm, src.nJoints, src.jointType, src.jointAxis, sT_fm, sT_mf);
-            if (RED) reduce_jacobian<RED>(row, Jfull, 6, fullDims, redDims, dtheta_dalpha, mapping);
-            row[d] = c.residual;
-            row[d + 1] = (float)(0.5 * (double)c.residual * (double)c.residual);
-            row[d + 2] = 1.0f;
-        }
-        __syncthreads();
-        if (nActive) acc.accumulate(rows, ld, nActive);
-        __syncthreads();
-    }
-    acc.store(slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * sys_size(d), sys_size(d));
+    ne_intersection_body<PPT, RED>(sites, nSites, src_in, dst_in, T_ds_sd, redDims, dtheta_dalpha, mapping, slabs, tabStride, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // counters (intersection.cu:11-64, :315-365)
@@ -294,6 +189,21 @@ static int launch_inter_dev(const float *d_sites, int nSites, int fullDims, int 
 #undef DARTK_LAUNCH_INTER
     DARTK_HIP(hipGetLastError());
     return launch_reduce_slabs(lane_partials(ws), nBlocks, S, d_result, 1, st);
+}
+
+size_t ne_self_lds_bytes(const ModelView &m, int redDims, int red) {
+    const int fullDims = 6 + m.nJoints;
+    const int d = (red ? redDims : fullDims) - 6;
+    size_t words = 24 * (size_t)m.nFrames + (size_t)NE_BLOCK * row_len(d, false) + 8;
+    if (red) words += (size_t)NE_BLOCK * ((fullDims - 6) | 1);
+    return words * sizeof(float);
+}
+size_t ne_inter_lds_bytes(const ModelView &src, const ModelView &dst, int redDims, int red) {
+    const int fullDims = 6 + src.nJoints;
+    const int d = red ? redDims : fullDims;
+    size_t words = 24 * (size_t)(src.nFrames + dst.nFrames) + (size_t)NE_BLOCK * row_len(d, false) + 8;
+    if (red) words += (size_t)NE_BLOCK * (fullDims | 1);
+    return words * sizeof(float);
 }
 
 // T_ds = T_mc(dst) * T_cm(src) and its inverse from the models' device poses (optimizer.cpp:396-397)

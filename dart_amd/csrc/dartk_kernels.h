@@ -96,6 +96,33 @@ int gn_ne_self_any(int red, const float *d_sites, int nSites, int fullDims, int 
 int gn_ne_inter_any(int red, const float *d_sites, int nSites, int fullDims, int redDims, Model *src, Model *dst,
                     const float *d_A, const int *d_map, float *d_T_scratch24, float *d_result, hipStream_t st);
 
+// ---- several term kernels in ONE launch (the single-frame multi-model loop, dartk_multi.hip) ---------------------------------
+// A union launch is a list of segments; segment i owns the workgroups [first, first + count) of the grid and runs one kernel
+// body (dartk_ne_bodies.h, the ray-cast trace) on them with its own arguments, as if it had been launched alone with `count`
+// workgroups. The table lives in device memory (written once per call: nothing in it changes between iterations).
+struct MultiArgs;
+enum UnionKind { UK_TRACE = 0, UK_ASSOC = 1, UK_SELF = 2, UK_INTER = 3, UK_M2O = 4, UK_O2M = 5 };
+struct UnionSeg {
+    int first, count, kind, red;        // red: 0 full pose, 1 linear reduction, 2 parameter map (the body's RED)
+    ModelView m, m2;                    // the term's model (the source model of an intersection) / the destination model
+    float *slabs;                       // the term's partial systems [count][S]
+    int redDims; const float *A; const int *map;
+    const float4 *sites; int nSites; const int *pot;                                   // intersections
+    float flx, fly, ppx, ppy; int width, height; float2 *trace;                       // trace
+    const float4 *vert; int nPix; const MultiArgs *assocArgs; int *lastElement; const int *validIdx, *nValid;   // association
+    const float4 *pred; int nPred; const float *T_gc; int *numPredictions;            // mod->obs
+    const dartk_da_point *pts; float huberDelta; const int *count_;                   // obs->mod (list length on the device)
+};
+static constexpr int kMaxUnionSegs = 16;
+struct UnionTable { int nSeg, pad; UnionSeg seg[kMaxUnionSegs]; };
+// ppt: 1 (every system of the launch has at most NE_BLOCK entries) or 3 (at most 3 NE_BLOCK)
+// group: 0 = a table of trace / association / intersection segments, 1 = a table of mod->obs / obs->mod segments
+int gn_launch_union(const UnionTable *d_table, int totalBlocks, int ppt, int group, size_t ldsBytes, hipStream_t st);
+size_t ne_mod2obs_lds_bytes(const ModelView &m, int d, int red);
+size_t ne_obs2mod_lds_bytes(const ModelView &m, int d, int red);
+size_t ne_self_lds_bytes(const ModelView &m, int redDims, int red);
+size_t ne_inter_lds_bytes(const ModelView &src, const ModelView &dst, int redDims, int red);
+
 // optional per-kernel-class timing with HIP events on the launch stream (dartk_profile_begin / _end)
 int prof_push(int cls, hipStream_t st);       // returns an event-pair index or -1 when profiling is off
 void prof_pop(int idx, hipStream_t st);

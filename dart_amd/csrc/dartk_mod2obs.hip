@@ -6,6 +6,7 @@
 #include "dartk_reduce.h"
 #include "dartk_kernels.h"
 #include "dartk_raycast.h"
+#include "dartk_ne_bodies.h"
 
 #include <cstdlib>
 
@@ -461,28 +462,27 @@ replay_tables_kernel(ModelView m_in, float flx, float fly, float ppx, float ppy,
 }
 
 template <int PPT, int RED, bool TRUNC, bool REPLAY = false>
-__global__ void __launch_bounds__(NE_BLOCK)
-ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, ModelView m_in, const float *__restrict__ T_gc_in,
+__device__ __forceinline__ void ne_mod2obs_body(const float4 *__restrict__ pred, int nPix, int modelNum, ModelView m_in, const float *__restrict__ T_gc_in,
                   float truncationDist, int redDims, const float *__restrict__ dtheta_dalpha, const int *__restrict__ mapping,
                   float *__restrict__ slabs, int *__restrict__ numPredictions, ReplayArgs ra, FrameBatch fb, int tgcStride,
-                  const int *__restrict__ nItems) {
+                  const int *__restrict__ nItems, int bx, int gx, int by) {
     extern __shared__ float lds[];
 #ifdef DARTK_STAMPS
     unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     M2O_STAMP(0);
     ModelView m = m_in;
-    select_frame(m, blockIdx.y);                    // frame of a batch (0 otherwise)
-    pred += (size_t)blockIdx.y * fb.pred;
-    T_gc_in += (size_t)blockIdx.y * tgcStride;
-    numPredictions += (size_t)blockIdx.y * fb.counts;
+    select_frame(m, by);                    // frame of a batch (0 otherwise)
+    pred += (size_t)by * fb.pred;
+    T_gc_in += (size_t)by * tgcStride;
+    numPredictions += (size_t)by * fb.counts;
     if (REPLAY) {       // the frame's slice of the trace buffer (fb.trace floats apart) and of the prediction maps
-        ra.trace += (size_t)blockIdx.y * (fb.trace / 2);
-        ra.predOut += (size_t)blockIdx.y * fb.pred;
-        if (ra.tables) ra.tables += (size_t)blockIdx.y * ra.tablesStride;
+        ra.trace += (size_t)by * (fb.trace / 2);
+        ra.predOut += (size_t)by * fb.pred;
+        if (ra.tables) ra.tables += (size_t)by * ra.tablesStride;
     }
     // hit-list form (batches): `pred` holds the frame's hits back to back, nItems[frame] of them (raycast_replay_multi_rows_kernel)
-    if (nItems) nPix = nItems[(size_t)blockIdx.y * fb.counts];
+    if (nItems) nPix = nItems[(size_t)by * fb.counts];
     const int fullDims = 6 + m.nJoints;
     const int d = RED ? redDims : fullDims;
     const int ld = row_len(d, false);
@@ -504,7 +504,7 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
     const int nT = 12 * m.nFrames, nTab = (REPLAY && ra.tables) ? 28 * m.nSdfs + 1 : 0;
     const bool batched = nT <= QS * NE_BLOCK && nTab <= QS * NE_BLOCK;
     float4 pcFirst = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (REPLAY && blockIdx.x * NE_BLOCK + (int)threadIdx.x < nPix) pcFirst = ra.predOut[blockIdx.x * NE_BLOCK + threadIdx.x];
+    if (REPLAY && bx * NE_BLOCK + (int)threadIdx.x < nPix) pcFirst = ra.predOut[bx * NE_BLOCK + threadIdx.x];
     // the label -> frame -> dependency-mask chain of a contributing pixel is served from LDS
     for (int i = threadIdx.x; i < 2 * m.nFrames + m.nSdfs; i += NE_BLOCK)
         sDep[i] = i < 2 * m.nFrames ? reinterpret_cast<const unsigned *>(m.depMask)[i] : (unsigned)m.sdfFrame[i - 2 * m.nFrames];
@@ -550,7 +550,7 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
     int myCount = 0;
     M2O_STAMP(1);
     const int nTiles = (nPix + NE_BLOCK - 1) / NE_BLOCK;
-    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+    for (int tile = bx; tile < nTiles; tile += gx) {
         const int index = tile * NE_BLOCK + threadIdx.x;
         bool active = false;
         f3 pm, pg;
@@ -559,7 +559,7 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
         if (index < nPix) {
             float4 pc;
             if (REPLAY) {       // the pixel's prediction is formed here from the per-SDF traces and kept for the caller
-                pc = tile == (int)blockIdx.x ? pcFirst : ra.predOut[index];
+                pc = tile == (int)bx ? pcFirst : ra.predOut[index];
                 M2O_STAMP(2);
                 if (ra.modelNum == 0) { pc.z = 0; pc.w = -1; }
                 float closestT = 10000;
@@ -609,13 +609,95 @@ ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, Model
         myCount += nActive;
         __syncthreads();
     }
-    acc.store(slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * sys_size(d), sys_size(d));
+    acc.store(slabs + ((size_t)by * gx + bx) * sys_size(d), sys_size(d));
     if (threadIdx.x == 0 && myCount) atomicAdd(numPredictions, myCount);
 #ifdef DARTK_STAMPS
     M2O_STAMP(7);
-    if (REPLAY && threadIdx.x == 0 && blockIdx.x < 1024)
-        for (int i = 0; i < 8; ++i) g_m2oStamps[8 * blockIdx.x + i] = stp[i];
+    if (REPLAY && threadIdx.x == 0 && bx < 1024)
+        for (int i = 0; i < 8; ++i) g_m2oStamps[8 * bx + i] = stp[i];
 #endif
+}
+
+template <int PPT, int RED, bool TRUNC, bool REPLAY = false>
+__global__ void __launch_bounds__(NE_BLOCK)
+ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, ModelView m_in, const float *__restrict__ T_gc_in,
+                  float truncationDist, int redDims, const float *__restrict__ dtheta_dalpha, const int *__restrict__ mapping,
+                  float *__restrict__ slabs, int *__restrict__ numPredictions, ReplayArgs ra, FrameBatch fb, int tgcStride,
+                  const int *__restrict__ nItems) {
+    ne_mod2obs_body<PPT, RED, TRUNC, REPLAY>(pred, nPix, modelNum, m_in, T_gc_in, truncationDist, redDims, dtheta_dalpha, mapping, slabs, numPredictions, ra, fb, tgcStride, nItems, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+
+// -----------------------------------------------------------------------------------------------------
+// Several term kernels in one launch (UnionTable, dartk_kernels.h): the workgroup finds its segment and runs that segment's body
+// with its virtual index. Bodies of different terms never share a workgroup, so LDS and barriers are each body's own.
+// -----------------------------------------------------------------------------------------------------
+// GROUP 0: trace / association / intersection bodies, GROUP 1: mod->obs / obs->mod bodies -- two kernels, each with the register
+// budget of its own bodies. (Measured: with the intersection bodies, 150 registers, moved to group 1 the first launch is no shorter
+// -- it lasts as long as the trace's stragglers, 40 us at 3 or at 8 waves per SIMD -- and the second grows from 26 to 33 us.)
+template <int PPT, int GROUP>
+__global__ void __launch_bounds__(NE_BLOCK)
+union_terms_kernel(const UnionTable *__restrict__ t) {
+    extern __shared__ float lds[];
+    int s = 0;
+    const int n = t->nSeg;
+    while (s + 1 < n && (int)blockIdx.x >= t->seg[s + 1].first) ++s;
+    const UnionSeg &g = t->seg[s];
+    const int bx = (int)blockIdx.x - g.first, gx = g.count;
+    const FrameBatch one{1, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (GROUP == 0) {
+    switch (g.kind) {
+    case UK_TRACE: {
+        int *sR = reinterpret_cast<int *>(lds);
+        stage_ray_rects(g.m, 0.0f, g.flx, g.fly, g.ppx, g.ppy, g.width, g.height, sR);
+        constexpr int W = NE_BLOCK / 64;
+        raycast_trace_tasks(bx * W + (int)(threadIdx.x >> 6), gx * W, sR, g.flx, g.fly, g.ppx, g.ppy, g.width, g.height, g.m, g.trace, 0.0f);
+        break;
+    }
+    case UK_ASSOC:
+        assoc_multi_body<false, true>(g.vert, g.nPix, g.assocArgs, g.lastElement, nullptr, nullptr, one, g.validIdx, g.nValid, bx, gx, 0);
+        break;
+    case UK_SELF:
+        if (g.red == 0) ne_self_intersection_body<PPT, 0>(g.sites, g.nSites, g.m, g.pot, g.redDims, g.A, g.map, g.slabs, bx, gx, 0);
+        else if (g.red == 1) ne_self_intersection_body<PPT, 1>(g.sites, g.nSites, g.m, g.pot, g.redDims, g.A, g.map, g.slabs, bx, gx, 0);
+        else ne_self_intersection_body<PPT, 2>(g.sites, g.nSites, g.m, g.pot, g.redDims, g.A, g.map, g.slabs, bx, gx, 0);
+        break;
+    case UK_INTER:
+        if (g.red == 0) ne_intersection_body<PPT, 0>(g.sites, g.nSites, g.m, g.m2, nullptr, g.redDims, g.A, g.map, g.slabs, 0, bx, gx, 0);
+        else if (g.red == 1) ne_intersection_body<PPT, 1>(g.sites, g.nSites, g.m, g.m2, nullptr, g.redDims, g.A, g.map, g.slabs, 0, bx, gx, 0);
+        else ne_intersection_body<PPT, 2>(g.sites, g.nSites, g.m, g.m2, nullptr, g.redDims, g.A, g.map, g.slabs, 0, bx, gx, 0);
+        break;
+    default: break;
+    }
+    } else {
+    switch (g.kind) {
+    case UK_M2O:
+        if (g.red == 0) ne_mod2obs_body<PPT, 0, false, false>(g.pred, g.nPred, g.m.modelId, g.m, g.T_gc, 0.f, g.redDims, g.A, g.map, g.slabs, g.numPredictions, ReplayArgs{}, one, 0, nullptr, bx, gx, 0);
+        else if (g.red == 1) ne_mod2obs_body<PPT, 1, false, false>(g.pred, g.nPred, g.m.modelId, g.m, g.T_gc, 0.f, g.redDims, g.A, g.map, g.slabs, g.numPredictions, ReplayArgs{}, one, 0, nullptr, bx, gx, 0);
+        else ne_mod2obs_body<PPT, 2, false, false>(g.pred, g.nPred, g.m.modelId, g.m, g.T_gc, 0.f, g.redDims, g.A, g.map, g.slabs, g.numPredictions, ReplayArgs{}, one, 0, nullptr, bx, gx, 0);
+        break;
+    default:        // UK_O2M
+        if (g.red == 0) ne_obs2mod_body<PPT, 0>(g.pts, g.vert, g.nPix, g.m, g.huberDelta, g.redDims, g.A, g.map, g.slabs, g.count_, one, bx, gx, 0);
+        else if (g.red == 1) ne_obs2mod_body<PPT, 1>(g.pts, g.vert, g.nPix, g.m, g.huberDelta, g.redDims, g.A, g.map, g.slabs, g.count_, one, bx, gx, 0);
+        else ne_obs2mod_body<PPT, 2>(g.pts, g.vert, g.nPix, g.m, g.huberDelta, g.redDims, g.A, g.map, g.slabs, g.count_, one, bx, gx, 0);
+        break;
+    }
+    }
+}
+
+template <int PPT, int GROUP>
+static int launch_union(const UnionTable *d_table, int totalBlocks, size_t ldsBytes, hipStream_t st) {
+    auto kfn = union_terms_kernel<PPT, GROUP>;
+    if (ldsBytes > 64 * 1024) DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+    hipLaunchKernelGGL(kfn, dim3(totalBlocks), dim3(NE_BLOCK), ldsBytes, st, d_table);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
+int gn_launch_union(const UnionTable *d_table, int totalBlocks, int ppt, int group, size_t ldsBytes, hipStream_t st) {
+    DARTK_REQUIRE(ldsBytes <= 160 * 1024, "LDS requirement %zu exceeds 160 KiB", ldsBytes);
+    DARTK_REQUIRE((ppt == 1 || ppt == 3) && (group == 0 || group == 1), "union launch: unsupported accumulator width %d / group %d", ppt, group);
+    if (ppt == 1) return group == 0 ? launch_union<1, 0>(d_table, totalBlocks, ldsBytes, st) : launch_union<1, 1>(d_table, totalBlocks, ldsBytes, st);
+    return group == 0 ? launch_union<3, 0>(d_table, totalBlocks, ldsBytes, st) : launch_union<3, 1>(d_table, totalBlocks, ldsBytes, st);
 }
 
 size_t ne_mod2obs_lds_bytes(const ModelView &m, int d, int red) {

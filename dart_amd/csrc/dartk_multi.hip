@@ -10,6 +10,7 @@
 #include "dartk_reduce.h"
 #include "dartk_kernels.h"
 #include "dartk_fk.h"
+#include "dartk_raycast.h"
 
 #include <string.h>
 #include <vector>
@@ -410,6 +411,8 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     const size_t cntInts = 2 * (size_t)DARTK_MAX_MODELS * nFrames + 4;      // + the iteration counter
     size_t floatsSmall = tableFloats + (size_t)nFrames * (tabStride + sysFloats);
     size_t total = argBytes + sizeof(int) * cntInts + sizeof(float) * floatsSmall + 1024;
+    const size_t o_union = (total + 255) / 256 * 256;          // two UnionTable blocks (the single-frame loop's shared launches)
+    total = o_union + 2 * ((sizeof(UnionTable) + 255) / 256 * 256);
     size_t o_pose = 0, o_obs = 0, o_tmp = 0, o_pred = 0, o_pts = 0;
     if (batch) {
         auto take = [&](size_t bytes) { size_t at = (total + 255) / 256 * 256; total = at + bytes; return at; };
@@ -549,14 +552,30 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     }
     // generateObsSdf per model with its start pose (optimizer.cpp:574-580); the full-pose mod->obs wrapper works in that frame
     if (useB) {
-        for (int m = 0; m < n; ++m) {
-            ProfScope ps(DARTK_PROF_OBS_SDF, st);
-            rc = gn_obs_sdf_build(d_vert, width, height, mods[m], o->focalLength, st);
-            if (rc) return rc;
-            DARTK_HIP(hipMemcpy2DAsync(T_obs[m], sizeof(float) * (batch ? tabStride : 12), mods[m]->v.T_mc,
-                                       sizeof(float) * (batch ? mods[m]->v.poseStride : 12), 12 * sizeof(float), nFrames,
-                                       hipMemcpyDeviceToDevice, st));
+        // a single frame: the builds of the models are independent (each has its own volumes): the first runs here, the others
+        // beside it on a side stream, joined before the loop
+        const bool sideBuilds = !batch && n > 1 && !prof_enabled() && getenv("DARTK_MULTI_ONE_STREAM") == nullptr;
+        if (sideBuilds) {
+            DARTK_HIP(hipEventRecord(ws->evFork, st));
+            DARTK_HIP(hipStreamWaitEvent(ws->auxStream, ws->evFork, 0));
         }
+        for (int m = 0; m < n; ++m) {
+            hipStream_t sb = (sideBuilds && m > 0) ? ws->auxStream : st;
+            ProfScope ps(DARTK_PROF_OBS_SDF, sb);
+            rc = gn_obs_sdf_build(d_vert, width, height, mods[m], o->focalLength, sb);
+            if (rc == DARTK_OK && hipMemcpy2DAsync(T_obs[m], sizeof(float) * (batch ? tabStride : 12), mods[m]->v.T_mc,
+                                                   sizeof(float) * (batch ? mods[m]->v.poseStride : 12), 12 * sizeof(float), nFrames,
+                                                   hipMemcpyDeviceToDevice, sb) != hipSuccess) {
+                set_error("copy of the observation-SDF pose failed");
+                rc = DARTK_ERR_HIP;
+            }
+            if (rc) break;
+        }
+        if (sideBuilds) {       // (also on an error: the caller's stream stays ordered after the side stream)
+            (void)hipEventRecord(ws->evObs, ws->auxStream);
+            (void)hipStreamWaitEvent(st, ws->evObs, 0);
+        }
+        if (rc) return rc;
     }
     // Three chains per iteration meet only in the solve: ray-cast -> cull -> mod->obs (the longest, on the caller's stream),
     // association -> obs->mod, and the intersection terms; the two shorter ones run on the side streams, each term wrapper
@@ -587,8 +606,160 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     } joinGuard{ws, st, stA, stC, false};
     // both counter arrays start at zero; every solve launch leaves them cleared for the next iteration
     DARTK_HIP(hipMemsetAsync(d_countA, 0, 2 * (size_t)DARTK_MAX_MODELS * nFrames * sizeof(int), st));
+    // ---- the single-frame loop on ONE stream with shared launches (the C2 recipe): per iteration
+    //   [trace of every model | association | self- and pairwise intersection terms]  ->  replay + cull
+    //   ->  [mod->obs of every model | obs->mod of every model]  ->  one reduction of all partial systems  ->  solve
+    // five launches and no event instead of ~15 launches and 7 event calls on three streams: the loop was paced by the host's
+    // enqueueing (tools/time_enqueue_multi.py), not by the device. The terms run the same bodies (dartk_ne_bodies.h) on the same
+    // data; only the number of workgroups per term -- the partition of the fixed-order sums -- is this path's own.
+    UnionTable *d_u1 = reinterpret_cast<UnionTable *>((char *)base + o_union);
+    UnionTable *d_u2 = reinterpret_cast<UnionTable *>((char *)base + o_union + (sizeof(UnionTable) + 255) / 256 * 256);
+    int u1Blocks = 0, u2Blocks = 0, unionPpt = 1, nUnionJobs = 0;
+    size_t u1Lds = 0, u2Lds = 0;
+    ReduceJob unionJobs[kMaxReduceJobs];
+    bool unionPath = !batch && n <= 3 && o->numIterations > 0 && nPriors >= 0 && getenv("DARTK_MULTI_NO_UNION") == nullptr &&
+                     getenv("DARTK_MULTI_ONE_STREAM") == nullptr && !prof_enabled();
+    if (unionPath) {
+        int maxS = 1;
+        for (int m = 0; m < n && unionPath; ++m) {
+            const ModelView &v = mods[m]->v;
+            const MultiSolveModel &sm = h.m[m];
+            if (sys_size(sm.dims) > maxS) maxS = sys_size(sm.dims);
+            if (useB && (v.nSdfs > NE_BLOCK || v.nSdfs > kMaxRaySdfs)) unionPath = false;
+            if (sm.sysC && mm[m].nCloud <= 0) unionPath = false;
+            for (int d = 0; d < n; ++d) if (sm.sysI[d] && mm[m].nCloud <= 0) unionPath = false;
+        }
+        if (maxS > 3 * NE_BLOCK) unionPath = false;
+        if (useA && (assocStageBytes == 0 || assocStageBytes > 64 * 1024)) unionPath = false;
+        unionPpt = maxS <= NE_BLOCK ? 1 : 3;
+    }
+    if (unionPath) {
+        static thread_local UnionTable t1, t2;
+        memset(&t1, 0, sizeof(t1)); memset(&t2, 0, sizeof(t2));
+        size_t slabFloats = 0;
+        auto seg = [&](UnionTable &t, int &blocks, int kind, int count) -> UnionSeg & {
+            UnionSeg &g = t.seg[t.nSeg++];
+            g.first = blocks; g.count = count; g.kind = kind;
+            blocks += count;
+            return g;
+        };
+        auto slab = [&](UnionSeg &g, int S, float *result, const int *count, int keep, int minCount) {
+            g.slabs = reinterpret_cast<float *>(slabFloats);        // offset for now: the buffer is sized below
+            unionJobs[nUnionJobs++] = ReduceJob{g.slabs, result, count, g.count, S, keep, minCount};
+            slabFloats += ((size_t)g.count * S + 63) / 64 * 64;
+        };
+        const int tilesPix = (nPix + NE_BLOCK - 1) / NE_BLOCK;
+        if (useB) {
+            for (int m = 0; m < n; ++m) {      // the traces: the launch's longest workgroups first
+                const ModelView &v = mods[m]->v;
+                const long long tasks = (long long)((o->predWidth + 7) / 8) * ((o->predHeight + 7) / 8) * v.nSdfs;
+                const long long want = (tasks + NE_BLOCK / 64 - 1) / (NE_BLOCK / 64);
+                UnionSeg &g = seg(t1, u1Blocks, UK_TRACE, (int)(want < 2048 ? want : 2048));
+                g.m = v; g.flx = o->predFl[0]; g.fly = o->predFl[1]; g.ppx = (float)(o->predWidth / 2); g.ppy = (float)(o->predHeight / 2);
+                g.width = o->predWidth; g.height = o->predHeight;
+                g.trace = reinterpret_cast<float2 *>(ws->rayBuf + traceOff[m]);
+                if (u1Lds < sizeof(int) * kRectInts) u1Lds = sizeof(int) * kRectInts;
+            }
+        }
+        if (useA) {
+            UnionSeg &g = seg(t1, u1Blocks, UK_ASSOC, tilesPix < 2048 ? tilesPix : 2048);
+            g.vert = (const float4 *)d_vert; g.nPix = nPix; g.assocArgs = (const MultiArgs *)d_assocArgs; g.lastElement = d_countA;
+            g.validIdx = d_validIdx; g.nValid = d_nValid;
+            if (u1Lds < assocStageBytes) u1Lds = assocStageBytes;
+        }
+        for (int m = 0; m < n; ++m) {
+            const MultiSolveModel &sm = h.m[m];
+            const ModelView &v = mods[m]->v;
+            const int tiles = (mm[m].nCloud + NE_BLOCK - 1) / NE_BLOCK;
+            const int blocks = tiles < kMaxPartialBlocks ? tiles : kMaxPartialBlocks;
+            if (sm.sysC) {
+                UnionSeg &g = seg(t1, u1Blocks, UK_SELF, blocks);
+                g.red = sm.redType; g.m = v; g.sites = (const float4 *)mm[m].d_cloud; g.nSites = mm[m].nCloud; g.pot = mm[m].d_potential;
+                g.redDims = sm.dims; g.A = mm[m].d_A; g.map = mm[m].d_map;
+                slab(g, sys_size(sm.dims - 6), sysC[m], nullptr, 1, 0);
+                const size_t l = ne_self_lds_bytes(v, sm.dims, sm.redType);
+                if (u1Lds < l) u1Lds = l;
+            }
+            for (int d = 0; d < n; ++d) {
+                if (!sm.sysI[d]) continue;
+                UnionSeg &g = seg(t1, u1Blocks, UK_INTER, blocks);
+                g.red = sm.redType; g.m = v; g.m2 = mods[d]->v; g.sites = (const float4 *)mm[m].d_cloud; g.nSites = mm[m].nCloud;
+                g.redDims = sm.dims; g.A = mm[m].d_A; g.map = mm[m].d_map;
+                slab(g, sys_size(sm.dims), sysI[m][d], nullptr, 1, 0);
+                const size_t l = ne_inter_lds_bytes(v, mods[d]->v, sm.dims, sm.redType);
+                if (u1Lds < l) u1Lds = l;
+            }
+        }
+        for (int m = 0; m < n; ++m) {
+            const MultiSolveModel &sm = h.m[m];
+            const ModelView &v = mods[m]->v;
+            if (useB) {
+                const int tiles = (nPred + NE_BLOCK - 1) / NE_BLOCK;
+                UnionSeg &g = seg(t2, u2Blocks, UK_M2O, tiles < kMaxPartialBlocks ? tiles : kMaxPartialBlocks);
+                g.red = sm.redType; g.m = v; g.pred = (const float4 *)d_prediction; g.nPred = nPred;
+                g.T_gc = sm.redType == 0 ? T_obs[m] : v.T_mc;        // (reduced wrappers use the model's current T_mc, modToObs.cu:851-988)
+                g.numPredictions = d_countB + m; g.redDims = sm.dims; g.A = mm[m].d_A; g.map = mm[m].d_map;
+                slab(g, sys_size(sm.dims), sysB[m], nullptr, 1, 0);
+                const size_t l = ne_mod2obs_lds_bytes(v, sm.dims, sm.redType);
+                if (u2Lds < l) u2Lds = l;
+            }
+            if (useA) {
+                UnionSeg &g = seg(t2, u2Blocks, UK_O2M, tilesPix < 512 ? tilesPix : 512);
+                g.red = sm.redType; g.m = v; g.pts = ptsList[m]; g.vert = (const float4 *)d_vert; g.nPix = nPix; g.huberDelta = o->huberDelta;
+                g.count_ = d_countA + m; g.redDims = sm.dims; g.A = mm[m].d_A; g.map = mm[m].d_map;
+                slab(g, sys_size(sm.dims), sysA[m], d_countA + m, 0, 10);
+                const size_t l = ne_obs2mod_lds_bytes(v, sm.dims, sm.redType);
+                if (u2Lds < l) u2Lds = l;
+            }
+        }
+        rc = ensure_partials(ws, (slabFloats + kPartialLanes - 1) / kPartialLanes + 64);    // (the three lanes are one buffer here)
+        if (rc) return rc;
+        for (UnionTable *t : {&t1, &t2})
+            for (int i = 0; i < t->nSeg; ++i)
+                if (t->seg[i].kind >= UK_SELF) t->seg[i].slabs = ws->partials + reinterpret_cast<size_t>(t->seg[i].slabs);
+        for (int i = 0; i < nUnionJobs; ++i) unionJobs[i].slabs = ws->partials + reinterpret_cast<size_t>(unionJobs[i].slabs);
+        for (int k = 0; k < 2; ++k) {
+            ArgSlot slot;
+            rc = arg_ring_acquire(sizeof(UnionTable), &slot);
+            if (rc) return rc;
+            memcpy(slot.h, k == 0 ? &t1 : &t2, sizeof(UnionTable));
+            DARTK_HIP(hipMemcpyAsync(k == 0 ? d_u1 : d_u2, slot.h, sizeof(UnionTable), hipMemcpyHostToDevice, st));
+            rc = arg_ring_release(slot, st);
+            if (rc) return rc;
+        }
+    }
+    auto run_union_iteration = [&](int it) -> int {
+        int rc = DARTK_OK;
+        if (u1Blocks > 0) {
+            ProfScope ps(DARTK_PROF_RAYCAST, st);
+            rc = gn_launch_union(d_u1, u1Blocks, unionPpt, 0, u1Lds, st);
+            if (rc) return rc;
+        }
+        if (useB) {
+            const float ppx = (float)(o->predWidth / 2), ppy = (float)(o->predHeight / 2);
+            rc = gn_launch_raycast_replay_cull_multi(o->predFl[0], o->predFl[1], ppx, ppy, o->predWidth, o->predHeight, n, mods, traceOff,
+                                                     d_prediction, d_vert, width, height, st, nullptr);
+            if (rc) return rc;
+        }
+        if (u2Blocks > 0) {
+            ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
+            rc = gn_launch_union(d_u2, u2Blocks, unionPpt, 1, u2Lds, st);
+            if (rc) return rc;
+        }
+        for (int i = 0; i < nUnionJobs; ++i) ws->reduceJobs[i] = unionJobs[i];
+        ws->nReduceJobs = nUnionJobs;
+        rc = flush_reduce_jobs(ws, st);
+        if (rc) return rc;
+        {
+            ProfScope ps(DARTK_PROF_SOLVE, st);
+            hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64), ldsSolve, st, d_args, it);
+        }
+        DARTK_HIP(hipGetLastError());
+        return DARTK_OK;
+    };
     auto run_iteration = [&](int it, int solveArg) -> int {
         int rc = DARTK_OK;
+        if (unionPath) return run_union_iteration(it);
         if (par) {      // the poses of this iteration are final on `st`
             DARTK_HIP(hipEventRecord(ws->evFork, st));
             DARTK_HIP(hipStreamWaitEvent(stA, ws->evFork, 0));

@@ -3,6 +3,7 @@
 #include "dartk_internal.h"
 #include "dartk_reduce.h"
 #include "dartk_kernels.h"
+#include "dartk_ne_bodies.h"
 
 namespace dartk {
 
@@ -62,20 +63,6 @@ assoc_single_kernel(const float4 *__restrict__ vert, const float4 *__restrict__ 
 // -----------------------------------------------------------------------------------------------------
 // association, multi model (obsToMod.cu:116-244): threshold inside the arg-min, no normal test.
 // -----------------------------------------------------------------------------------------------------
-struct MultiArgs {
-    int nModels;
-    ModelView m[DARTK_MAX_MODELS];
-    float distThr[DARTK_MAX_MODELS];
-    float planeOffset[DARTK_MAX_MODELS];
-    float pn[DARTK_MAX_MODELS][3];
-    dartk_da_point *pts[DARTK_MAX_MODELS];
-};
-
-// words of LDS per model in the staged form: T_mc | T_fm[nFrames] | SDF -> frame | SDF headers
-__host__ __device__ inline int assoc_stage_words(const ModelView &m) {
-    return 12 + 12 * m.nFrames + m.nSdfs + (int)(sizeof(SdfDev) / 4) * m.nSdfs;
-}
-
 // STAGED (the loops' launches: a chip-sized grid whose workgroups stride over the valid-pixel list): every model's transforms,
 // SDF -> frame table and SDF headers are copied to LDS once per workgroup; the per-(pixel, SDF) loop then reads them there instead
 // of through two dependent scalar loads per SDF (frame index, then its transform) and a header fetch from memory.
@@ -84,93 +71,7 @@ __global__ void __launch_bounds__(256)
 assoc_multi_kernel(const float4 *__restrict__ vert, int nPix, const MultiArgs *__restrict__ args,
                    int *__restrict__ lastElement, int *__restrict__ dbgDA, float *__restrict__ dbgErr, FrameBatch fb,
                    const int *__restrict__ validIdx, const int *__restrict__ nValid) {
-    extern __shared__ float lds[];
-    const int frame = blockIdx.y;                    // frame of a batch (0 otherwise)
-    vert += (size_t)frame * fb.vert;
-    lastElement += (size_t)frame * fb.counts;
-    if (STAGED) {
-        int off = 0;
-        const int nm = args->nModels;
-        for (int mi = 0; mi < nm; ++mi) {
-            const ModelView &m = args->m[mi];
-            const size_t po = (size_t)frame * (size_t)m.poseStride;
-            const int nT = 12 * m.nFrames, nS = m.nSdfs, nH = (int)(sizeof(SdfDev) / 4) * nS;
-            float *p = lds + off;
-            for (int i = threadIdx.x; i < 12 + nT; i += blockDim.x) p[i] = i < 12 ? m.T_mc[po + i] : m.T_fm[po + i - 12];
-            int *pi = reinterpret_cast<int *>(p + 12 + nT);
-            for (int i = threadIdx.x; i < nS; i += blockDim.x) pi[i] = m.sdfFrame[i];
-            const int *src = reinterpret_cast<const int *>(m.sdfs);
-            for (int i = threadIdx.x; i < nH; i += blockDim.x) pi[nS + i] = src[i];
-            off += assoc_stage_words(m);
-        }
-        __syncthreads();
-    }
-    // with a list of the frame's valid pixels (gn_valid_pixels) the workgroups stride over the list instead of the map: the
-    // launch then needs only as many workgroups as fill the chip, not one per 256 pixels of which most would find nothing
-    const int nItems = validIdx ? nValid[frame] : nPix;
-    for (int k0 = blockIdx.x * blockDim.x; k0 < nItems; k0 += gridDim.x * blockDim.x) {
-    const int k = k0 + threadIdx.x;
-    const int index = validIdx ? (k < nItems ? validIdx[(size_t)frame * nPix + k] : nPix) : k;
-    int aModel = -1, aGrid = -1;
-    float sdfError = 1e20f;
-    if (index < nPix) {
-        if (DBG) {
-            if (dbgDA) dbgDA[index] = -1;
-            if (dbgErr) dbgErr[index] = __builtin_nanf("");
-        }
-        const float4 xc = vert[index];
-        if (xc.w > 0) {
-            const int nModels = args->nModels;
-            int stageOff = 0;
-            for (int mi = 0; mi < nModels; ++mi) {
-                const ModelView &m = args->m[mi];
-                const size_t po = (size_t)frame * (size_t)m.poseStride;
-                const float *sM = lds + stageOff;                           // STAGED: this model's block
-                stageOff += STAGED ? assoc_stage_words(m) : 0;
-                const float *T_mc = STAGED ? sM : m.T_mc + po;
-                const f3 xm = se3_apply_w(T_mc, xc.x, xc.y, xc.z, xc.w);
-                f3 pn; pn.x = args->pn[mi][0]; pn.y = args->pn[mi][1]; pn.z = args->pn[mi][2];
-                if (!(dot(xm, pn) >= args->planeOffset[mi])) continue;
-                const float thr = args->distThr[mi];
-                const int slot = keep_slot(thr);
-                const float *T_fm = STAGED ? sM + 12 : m.T_fm + po;
-                const int *sFrame = STAGED ? reinterpret_cast<const int *>(sM + 12 + 12 * m.nFrames) : m.sdfFrame;
-                const SdfDev *sdfTab = STAGED ? reinterpret_cast<const SdfDev *>(sFrame + m.nSdfs) : m.sdfs;
-                for (int g = 0; g < m.nSdfs; ++g) {
-                    const int f = sFrame[g];
-                    const f3 xf = se3_apply_w(T_fm + 12 * f, xm.x, xm.y, xm.z, xc.w);
-                    const SdfDev &s = sdfTab[g];
-                    const f3 xg = grid_coords(s, xf);
-                    if (!in_bounds_grad_interp(s, xg) || !in_keep_box(s, slot, xg)) continue;
-                    const float d = sdf_value<CNT_ASSOC>(m.grids, s, xg) * s.res;
-                    if (d < sdfError) {
-                        if (d * d < thr * thr) { sdfError = d; aGrid = g; aModel = mi; }
-                    }
-                }
-            }
-            if (DBG && aModel != -1) {
-                if (dbgDA) dbgDA[index] = ((aModel << 16) | aGrid);
-                if (dbgErr) dbgErr[index] = sdfError;
-            }
-        }
-    }
-    const int lane = threadIdx.x & 63;
-    const int nModels = args->nModels;
-    for (int mi = 0; mi < nModels; ++mi) {     // per-model wave-aggregated append
-        const bool mine = (aModel == mi);
-        const unsigned long long mask = __ballot(mine);
-        if (!mask) continue;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&lastElement[mi], __popcll(mask));
-        base = __shfl(base, 0);
-        if (mine) {
-            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            dartk_da_point p;
-            p.index = index; p.dataAssociation = aGrid; p.error = sdfError;
-            args->pts[mi][(size_t)frame * fb.pts + base + __popcll(mask & lt)] = p;
-        }
-    }
-    }
+    assoc_multi_body<DBG, STAGED>(vert, nPix, args, lastElement, dbgDA, dbgErr, fb, validIdx, nValid, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -184,69 +85,7 @@ __global__ void __launch_bounds__(NE_BLOCK)
 ne_obs2mod_kernel(const dartk_da_point *__restrict__ pts, const float4 *__restrict__ vert, int nPoints, ModelView m_in,
                   float huberDelta, int redDims, const float *__restrict__ dtheta_dalpha,
                   const int *__restrict__ mapping, float *__restrict__ slabs, const int *__restrict__ d_count, FrameBatch fb) {
-    extern __shared__ float lds[];
-    ModelView m = m_in;
-    select_frame(m, blockIdx.y);                        // frame of a batch (0 otherwise)
-    pts += (size_t)blockIdx.y * fb.pts;
-    vert += (size_t)blockIdx.y * fb.vert;
-    if (d_count) nPoints = min(nPoints, d_count[(size_t)blockIdx.y * fb.counts]);      // device-resident loops: the list length stays on the device
-    const int fullDims = 6 + m.nJoints;
-    const int d = RED ? redDims : fullDims;
-    const bool drop = (RED != 0);
-    const int ld = row_len(d, drop);
-    float *sT_fm = lds;
-    float *sT_mf = sT_fm + 12 * m.nFrames;
-    SdfDev *sSdf = reinterpret_cast<SdfDev *>(sT_mf + 12 * m.nFrames);
-    float *sFull = reinterpret_cast<float *>(sSdf + m.nSdfs);          // [NE_BLOCK][fullDims|1] when RED
-    const int fullLd = fullDims | 1;
-    float *rows = sFull + (RED ? NE_BLOCK * fullLd : 0);
-    stage_model(m, sT_fm, sT_mf, sSdf);
-    float T_mc[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T_mc[i] = m.T_mc[i];
-    __syncthreads();
-
-    PairAcc<NE_BLOCK, PPT> acc;
-    acc.init(d, drop);
-
-    const int nTiles = (nPoints + NE_BLOCK - 1) / NE_BLOCK;
-    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
-        const int k = tile * NE_BLOCK + threadIdx.x;
-        float *row = rows + threadIdx.x * ld;
-        if (k < nPoints) {
-            const dartk_da_point pt = pts[k];
-            const float4 xc = vert[pt.index];
-            const f3 xm = se3_apply_w(T_mc, xc.x, xc.y, xc.z, xc.w);
-            const int g = pt.dataAssociation;
-            const int frame = m.sdfFrame[g];
-            const f3 xf = se3_apply_w(sT_fm + 12 * frame, xm.x, xm.y, xm.z, xc.w);
-            const SdfDev s = sSdf[g];
-            const f3 xg = grid_coords(s, xf);
-            const f3 gf = sdf_gradient<CNT_NE_O2M>(m.grids, s, xg);
-            const f3 gm = se3_rotate(sT_mf + 12 * frame, gf);
-            float *Jfull = RED ? (sFull + threadIdx.x * fullLd) : row;
-            error_jacobian<false>(Jfull, xm, xc.w, m.depMask[frame], gm, m.nJoints, m.jointType, m.jointAxis, sT_fm, sT_mf);
-            if (RED) reduce_jacobian<RED>(row, Jfull, 6, fullDims, redDims, dtheta_dalpha, mapping);
-            const float err = pt.error;
-            const bool inlier = fabsf(err) < huberDelta;
-            float r, E;
-            if (inlier) { r = -err; E = (float)(0.5 * (double)r * (double)r); }
-            else {
-                const float v = (err < 0) ? -huberDelta : huberDelta;
-                r = -v;
-                E = (float)((double)huberDelta * ((double)fabsf(err) - 0.5 * (double)huberDelta));
-            }
-            row[d] = r; row[d + 1] = E; row[d + 2] = 1.0f;
-            if (drop) {
-                for (int i = 0; i < d; ++i) row[d + 3 + i] = inlier ? row[i] : 0.0f;
-            }
-        }
-        __syncthreads();
-        const int n = min(NE_BLOCK, nPoints - tile * NE_BLOCK);
-        acc.accumulate(rows, ld, n);
-        __syncthreads();
-    }
-    acc.store(slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * sys_size(d), sys_size(d));
+    ne_obs2mod_body<PPT, RED>(pts, vert, nPoints, m_in, huberDelta, redDims, dtheta_dalpha, mapping, slabs, d_count, fb, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 size_t ne_obs2mod_lds_bytes(const ModelView &m, int d, int red) {
