@@ -170,7 +170,8 @@ def count_lookups(fn):
     return [int(v) for v in cnt]
 
 
-def roofline_entry(name, bytes_per_launch, lookups_per_launch, per_launch_us, batch=False, traffic_table=None, rocprof_table=None):
+def roofline_entry(name, bytes_per_launch, lookups_per_launch, per_launch_us, batch=False, traffic_table=None, rocprof_table=None,
+                   limiter_suffix="@batch"):
     """One kernel's roofline figures. achieved = algorithmic bytes of the work performed / the launch duration measured live with
     HIP events on the launch stream. `bound` names the roof the fraction is priced against (HBM bandwidth: every kernel of this
     path moves bytes, none is a GEMM); `limiter` says what the committed counter passes show actually bounds the kernel
@@ -180,7 +181,7 @@ def roofline_entry(name, bytes_per_launch, lookups_per_launch, per_launch_us, ba
     us = per_launch_us[name]
     ach = bytes_per_launch / (us * 1e-6) / 1e9
     traffic = pmc_traffic(name, PMC_TRAFFIC if traffic_table is None else traffic_table)
-    lim = LIMITERS.get(name + ("@batch" if batch and (name + "@batch") in LIMITERS else ""), {})
+    lim = LIMITERS.get(name + (limiter_suffix if batch and (name + limiter_suffix) in LIMITERS else ""), {})
     rp = rocprof_stats(name, batch, True, rocprof_table)
     e = {"bound": "hbm", "limiter": lim.get("limiter"), "limiter_evidence": lim.get("evidence"), "kernel": name,
          "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -548,7 +549,7 @@ def main():
                 if k in p_launch_us:
                     n_l = p_launches[k]
                     ents[k] = roofline_entry(k, bp[k] * nPF * iters / n_l, lkp.get(k, 0.0) * nPF * iters / n_l, p_launch_us, batch=True,
-                                             traffic_table=PMC_TRAFFIC_POSE_BATCH, rocprof_table=ROCPROF_POSE_BATCH)
+                                             traffic_table=PMC_TRAFFIC_POSE_BATCH, rocprof_table=ROCPROF_POSE_BATCH, limiter_suffix="@pose_batch")
             if ents:
                 dom = max(ents, key=lambda k: p_step_us.get(k, 0.0))
                 p_roof = dict(ents[dom])

@@ -3,7 +3,12 @@
   * the NoObs path (dartk_noobs_optimize_poses, optimizer.cpp:913-958), single candidates and a batch, and
   * the observation loop (dartk_optimize_poses_priors, optimizer.cpp:727-732, 757-759),
 against the CPU oracle, which tests/test_oracle_contact_update.py pins against an independent assembly of the reference's
-full system. Poses AND contact points are compared."""
+full system. Poses AND contact points are compared.
+
+PARITY UNPINNED against the reference itself: the reference holds no fixture for moving contact points, and sdf.cpp:13 calls an
+unqualified abs(dist) whose overload (float or the truncating int abs(int)) depends on the host toolchain the reference cannot
+be built with here; library and oracle both take the float reading. These tests pin the HIP path to the
+oracle's restatement, not to reference outputs."""
 import numpy as np
 import pytest
 

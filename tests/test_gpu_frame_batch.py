@@ -82,7 +82,7 @@ def test_frame_result_does_not_depend_on_the_batch(gpu):
     pinfo = tr.iteration_summaries.copy()
     assert np.array_equal(pinfo[:, 0, :, 3:5], info[perm][:, 0, :, 3:5])
     assert np.abs(pT - bT[perm]).max() < 2e-5 and np.abs(pa - ba[perm]).max() < 1e-4
-    # a batch of one and a chunked batch (DARTK_BATCH_CHUNK is read once per process: chunking is covered by the 1-frame call)
+    # a batch of one and a chunked batch (DARTK_BATCH_CHUNK is read on every call; the chunk seams are covered by tests/test_gpu_frame_batch_chunks.py)
     oT, oa = tr.optimizePosesBatch(vert[2:3].contiguous(), norm[2:3].contiguous(), T0[2:3], a0[2:3])
     assert np.abs(oT[0] - bT[2]).max() < 2e-5 and np.abs(oa[0] - ba[2]).max() < 1e-4
     # the tracker's own poses are untouched by a batch call
