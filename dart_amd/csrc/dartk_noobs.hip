@@ -205,10 +205,10 @@ __device__ __forceinline__ unsigned long long tile_candidates(const float *c, fl
 #ifndef NOOBS_WAVES_INTER
 #define NOOBS_WAVES_INTER 5
 #endif
+// (the body: workgroup bx of term termIdx; the kernels below are its wrappers)
 template <int TPT, int TYPE>
-__global__ void __launch_bounds__(NE_BLOCK) __attribute__((amdgpu_waves_per_eu(term_weighted(TYPE) ? NOOBS_WAVES_PRIORS : NOOBS_WAVES_INTER)))
-noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses, float *__restrict__ slabs, int termIdx, int potLdsInts,
-                   int flags) {
+__device__ __forceinline__ void noobs_terms_body(const NoObsProblem *__restrict__ P, float *__restrict__ poses, float *__restrict__ slabs,
+                                                 int termIdx, int potLdsInts, int flags, int bx) {
     extern __shared__ float lds[];
 #ifdef DARTK_STAMPS
     unsigned long long stampT = clock64();
@@ -320,7 +320,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         const ModelView &dm = (TYPE == TERM_SELF) ? src : dst;
         if (T.tiles && dm.nSdfs <= 64) {
             const int nT = (T.nPoints + NE_BLOCK - 1) / NE_BLOCK;
-            const int mine = ((int)blockIdx.x < nT) ? (nT - (int)blockIdx.x + T.nBlocks - 1) / T.nBlocks : 0;     // tiles of this workgroup
+            const int mine = (bx < nT) ? (nT - bx + T.nBlocks - 1) / T.nBlocks : 0;     // tiles of this workgroup
             float *endF = sFullJ + ((P->anyReduced) ? NOOBS_ROWS * fullLd : 0);
             sCull = reinterpret_cast<unsigned long long *>(lds + ((((int)(endF - lds)) + 1) & ~1));
             sCullSplit = reinterpret_cast<int *>(sCull + 4 * mine);
@@ -330,7 +330,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
             const float *sph = (TYPE == TERM_SELF) ? sSph(T.src) : sSph(T.dst);
             for (int w = threadIdx.x; w < 4 * mine; w += blockDim.x) {
                 const int seg = w & 1, k = w >> 1;
-                const int wt = ((int)blockIdx.x + (k >> 1) * T.nBlocks) * (NE_BLOCK / 64) + (k & 1);
+                const int wt = (bx + (k >> 1) * T.nBlocks) * (NE_BLOCK / 64) + (k & 1);
                 unsigned long long mask = ~0ull;
                 int split = -1;
                 if (wt < nWaveTiles) {
@@ -468,7 +468,7 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
         NOOBS_STAMP(5);
     };
     int pending = 0;
-    const int localBlock = blockIdx.x;
+    const int localBlock = bx;
     const int nTiles = (T.nPoints + NE_BLOCK - 1) / NE_BLOCK;
     for (int tile = localBlock; tile < nTiles; tile += T.nBlocks) {
         const int index = tile * NE_BLOCK + threadIdx.x;
@@ -750,6 +750,30 @@ noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses
 #undef sTf
 #undef sSph
 #undef uniOff
+}
+
+template <int TPT, int TYPE>
+__global__ void __launch_bounds__(NE_BLOCK) __attribute__((amdgpu_waves_per_eu(term_weighted(TYPE) ? NOOBS_WAVES_PRIORS : NOOBS_WAVES_INTER)))
+noobs_terms_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses, float *__restrict__ slabs, int termIdx, int potLdsInts,
+                   int flags) {
+    noobs_terms_body<TPT, TYPE>(P, poses, slabs, termIdx, potLdsInts, flags, (int)blockIdx.x);
+}
+
+// The intersection terms of an iteration (self, hand -> object, object -> hand ...) in ONE launch: workgroup blockIdx.x belongs to
+// the term whose range of workgroups holds it. Three launches of 2 x 4096 workgroups each end in a tail where the chip runs half
+// empty; one launch of 6 x 4096 has one tail. Terms [firstTerm, firstTerm + nUnion) must be self / pairwise terms of <= 32 dims.
+__global__ void __launch_bounds__(NE_BLOCK) __attribute__((amdgpu_waves_per_eu(NOOBS_WAVES_INTER)))
+noobs_inter_union_kernel(const NoObsProblem *__restrict__ P, float *__restrict__ poses, float *__restrict__ slabs, int firstTerm, int nUnion,
+                         int potLdsInts, int flags) {
+    int bx = (int)blockIdx.x, term = firstTerm;
+    for (int i = 0; i < nUnion; ++i) {
+        const int nb = P->term[firstTerm + i].nBlocks;
+        term = firstTerm + i;
+        if (bx < nb) break;
+        bx -= nb;
+    }
+    if (P->term[term].type == TERM_SELF) noobs_terms_body<0, TERM_SELF>(P, poses, slabs, term, potLdsInts, flags, bx);
+    else noobs_terms_body<0, TERM_INTER>(P, poses, slabs, term, potLdsInts, flags, bx);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -1037,7 +1061,25 @@ static int noobs_launch_term_ppt(NoObs *t, int term, int batch, hipStream_t st) 
 
 // one launch per term (the terms write disjoint slabs; the solve kernel that follows reads them all)
 static int noobs_launch_terms(NoObs *t, int batch, hipStream_t st) {
-    for (int i = 0; i < t->h.nTerms; ++i) {
+    // the leading run of self / pairwise terms that the matrix-core form covers shares one launch (noobs_inter_union_kernel)
+    int nUnion = 0, unionBlocks = 0;
+    size_t unionLds = 0;
+    if (getenv("DARTK_NOOBS_NO_MFMA") == nullptr && getenv("DARTK_NOOBS_NO_UNION") == nullptr) {
+        while (nUnion < t->h.nTerms && (t->h.term[nUnion].type == TERM_SELF || t->h.term[nUnion].type == TERM_INTER) && t->h.term[nUnion].dims <= 32) {
+            unionBlocks += t->h.term[nUnion].nBlocks;
+            if (t->ldsTerm[nUnion] > unionLds) unionLds = t->ldsTerm[nUnion];
+            ++nUnion;
+        }
+    }
+    if (nUnion < 2) nUnion = 0;
+    if (nUnion) {
+        ProfScope ps(DARTK_PROF_NOOBS_TERMS, st);
+        if (unionLds > 64 * 1024)
+            DARTK_HIP(hipFuncSetAttribute((const void *)noobs_inter_union_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)unionLds));
+        hipLaunchKernelGGL(noobs_inter_union_kernel, dim3(unionBlocks, batch), dim3(NE_BLOCK), unionLds, st, t->d, t->poses, t->slabs, 0, nUnion,
+                           t->potLdsInts, t->termFlags);
+    }
+    for (int i = nUnion; i < t->h.nTerms; ++i) {
         int rc;
         ProfScope ps(term_weighted(t->h.term[i].type) ? DARTK_PROF_NOOBS_PRIORS : DARTK_PROF_NOOBS_TERMS, st);
         switch (t->h.term[i].type) {
