@@ -73,7 +73,7 @@ ROCPROF_KERNELS = {
     "gn_reduce_kernel": [("gn_reduce_kernel", None)],
     "gn_solve_single_kernel": [("gn_solve_single_kernel", None)],
     "noobs_terms_kernel<priors>": [("noobs_terms_kernel", r"^\d+, [234]")],
-    "noobs_terms_kernel<intersection>": [("noobs_terms_kernel", r"^\d+, [01]")],
+    "noobs_terms_kernel<intersection>": [("noobs_inter_union_kernel", None), ("noobs_terms_kernel", r"^\d+, [01]")],
     "noobs_solve_kernel": [("noobs_solve_kernel", None)],
     "assoc_multi_kernel": [("assoc_multi_kernel", None)],
     "raycast_replay_kernel": [("raycast_replay_multi_rows_kernel", None), ("raycast_replay_multi_kernel", None), ("raycast_replay_kernel", None)],
@@ -108,10 +108,12 @@ def rocprof_stats(kernel, batch, retry=True, table=None):
 
 def l2_hit_rate(kernel):
     """launch-weighted L2 (TCC) hit rate of the kernel class in the committed counter pass (all its instantiations)"""
+    import re
     hit, n = 0.0, 0
-    for base, _ in ROCPROF_KERNELS.get(kernel, [(kernel, None)]):
+    for base, targs in ROCPROF_KERNELS.get(kernel, [(kernel, None)]):
         for key, v in L2_RATES.items():
-            if key.partition("<")[0] == base:
+            b, _, rest = key.partition("<")
+            if b == base and (not targs or "@batch" in targs or re.search(targs, rest.rstrip(">"))):
                 hit += v["hit_rate"] * v["launches"]
                 n += v["launches"]
     return round(hit / n, 4) if n else None
@@ -635,10 +637,12 @@ def main():
             # per candidate and pass: 40 B per contact prior / 16 B per cloud point + 32 B per trilinear lookup performed + partial
             # systems + the candidate's pose record (transforms of both models, read by every workgroup)
             pose_bytes = 4.0 * sum(24 + max(m.n_joints, 1) + 24 * m.n_frames for m in (gs.hand, gs.obj))
+            # intersection launches per pass: one (the terms share a launch, noobs_inter_union_kernel) or one per term; the class's
+            # figure is the terms' sum over the class's launches
+            n_il = max(launches.get(K_I, 1.0) / max(launches.get(K_P, 1.0), 1.0), 1.0)
             bytes_per_launch = {K_P: (40.0 * Q + 32.0 * lk_prior + 4.0 * slab_prior + pose_bytes) * len(idx),
-                                # three intersection kernels per pass: the figure is their sum over the class's launches
-                                K_I: (16.0 * Cn + 32.0 * lk_inter + 4.0 * slab_inter + 3 * pose_bytes) * len(idx) / 3.0}
-            lk_launch = {K_P: lk_prior * len(idx), K_I: lk_inter * len(idx) / 3.0}
+                                K_I: (16.0 * Cn + 32.0 * lk_inter + 4.0 * slab_inter + 3 * pose_bytes) * len(idx) / n_il}
+            lk_launch = {K_P: lk_prior * len(idx), K_I: lk_inter * len(idx) / n_il}
             g_name = max((K_I, K_P), key=lambda k: per_step_us.get(k, 0.0))
             g_roof = roofline_entry(g_name, bytes_per_launch[g_name], lk_launch[g_name], per_launch_us, batch=True)
             g_roof.update({"per_step_us": per_step_from_rocprof(launches, True, [k for k in (K_I, K_P, "noobs_solve_kernel") if k in launches],

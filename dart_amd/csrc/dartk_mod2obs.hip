@@ -338,14 +338,17 @@ dt_pass_x_kernel(const float *__restrict__ in, float *__restrict__ out, int len,
     const int total = nl * len;
     for (int i = threadIdx.x; i < total; i += blockDim.x) lds[i] = in[(size_t)line0 * len + i];
     __syncthreads();
+    // (q - p)^2 + in[p] as ONE fma of the float difference: the square of an integer below 2^12 is exact, so the fma rounds the
+    // same sum once, as the multiply-then-add did -- two operations less per (q, p) pair
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
         const int l = i / len, q = i - l * len;
         const float *row = lds + l * len;
         float best = 3.0e38f;
+        float d = (float)q;
 #pragma unroll 8
         for (int p = 0; p < len; ++p) {
-            const int d = q - p;
-            best = fminf(best, (float)(d * d) + row[p]);
+            best = fminf(best, __builtin_fmaf(d, d, row[p]));
+            d -= 1.0f;
         }
         out[(size_t)line0 * len + i] = takeSqrt ? sqrtf(best) : best;
     }
@@ -374,14 +377,15 @@ dt_pass_strided_kernel(const float *__restrict__ in, float *__restrict__ out, in
     if (!ok) return;
     const int q0 = qc * DT_QCHUNK + g * 4;
     float b0 = 3.0e38f, b1 = 3.0e38f, b2 = 3.0e38f, b3 = 3.0e38f;
+    float d0 = (float)q0, d1 = (float)(q0 + 1), d2 = (float)(q0 + 2), d3 = (float)(q0 + 3);     // q - p as floats, one fma per pair (see above)
 #pragma unroll 8
     for (int p = 0; p < len; ++p) {
         const float v = lds[p * 64 + lx];
-        const int d0 = q0 - p, d1 = q0 + 1 - p, d2 = q0 + 2 - p, d3 = q0 + 3 - p;
-        b0 = fminf(b0, (float)(d0 * d0) + v);
-        b1 = fminf(b1, (float)(d1 * d1) + v);
-        b2 = fminf(b2, (float)(d2 * d2) + v);
-        b3 = fminf(b3, (float)(d3 * d3) + v);
+        b0 = fminf(b0, __builtin_fmaf(d0, d0, v));
+        b1 = fminf(b1, __builtin_fmaf(d1, d1, v));
+        b2 = fminf(b2, __builtin_fmaf(d2, d2, v));
+        b3 = fminf(b3, __builtin_fmaf(d3, d3, v));
+        d0 -= 1.0f; d1 -= 1.0f; d2 -= 1.0f; d3 -= 1.0f;
     }
     const float r[4] = {b0, b1, b2, b3};
 #pragma unroll

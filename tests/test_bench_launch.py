@@ -39,7 +39,7 @@ def test_rank_refuses_a_world_size_that_is_not_gpus():
 @pytest.mark.gpu
 def test_two_ranks_rehearsed_on_one_gpu(gpu):
     r = run(["--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1", "--repeats", "0", "--no-cpu-baseline",
-             "--grasp-steps", "1", "--multi-steps", "1", "--frames", "6"], timeout=900)
+             "--grasp-steps", "1", "--multi-steps", "1", "--frames", "6", "--pose-frames", "10", "--pose-steps", "1"], timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line, from rank 0: %r" % r.stdout[-2000:]
@@ -48,3 +48,4 @@ def test_two_ranks_rehearsed_on_one_gpu(gpu):
     assert j["batched_grasps"]["n_candidates"] == 4096 and j["batched_grasps"]["candidates_per_gpu"] == 2048
     assert j["multi_model_tracking"]["n_frames"] == 6 and j["multi_model_tracking"]["frames_per_gpu"] == 3
     assert len(j["batched_grasps"]["best_candidates"]) == 5
+    assert j["tracking_batch"]["n_frames"] == 10 and j["tracking_batch"]["frames_per_gpu"] == 5 and j["tracking_batch"]["value"] > 0

@@ -36,6 +36,8 @@ def per_kernel(path, counter):
 
 def short(name):
     n = name.split("(")[0].replace("void ", "").replace("dartk::", "")
+    if n.startswith("noobs_inter_union_kernel"):  # the intersection terms of an iteration in one launch
+        return "noobs_terms_kernel<intersection>"
     if n.startswith("noobs_terms_kernel<"):       # one instantiation per term type: keep them apart (bench.py's class names)
         typ = n[n.index("<") + 1:n.index(">")].split(",")[-1].strip()
         return "noobs_terms_kernel<priors>" if typ == "2" else "noobs_terms_kernel<intersection>"
