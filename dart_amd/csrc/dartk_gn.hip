@@ -47,15 +47,21 @@ void prof_pop(int idx, hipStream_t st) { (void)hipEventRecord(g_prof[idx].b, st)
 static constexpr int VC_BLOCK = 256;
 // zero2 (optional): two counters the iteration's kernels expect at zero (this is the first kernel of the call on its stream)
 // (both kernels: grid.y = frame of a batch; the frames' maps, counts, lists and totals lie nPix / gridDim.x / nPix / 1 apart)
+// masks: [frames][ceil(nPix / 64)] validity bits, read by valid_write_kernel (the map itself is read once per call)
 __global__ void __launch_bounds__(VC_BLOCK)
-valid_count_kernel(const float4 *__restrict__ vert, int nPix, int *__restrict__ blockCounts, int *__restrict__ zero2) {
+valid_count_kernel(const float4 *__restrict__ vert, int nPix, int *__restrict__ blockCounts, int *__restrict__ zero2,
+                   unsigned long long *__restrict__ masks) {
     __shared__ int wc[VC_BLOCK / 64];
     vert += (size_t)blockIdx.y * nPix;
     blockCounts += (size_t)blockIdx.y * gridDim.x;
+    masks += (size_t)blockIdx.y * ((nPix + 63) / 64);
     const int index = blockIdx.x * VC_BLOCK + threadIdx.x;
     const bool v = index < nPix && vert[index].w > 0;
     const unsigned long long mask = __ballot(v);
-    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(mask);
+    if ((threadIdx.x & 63) == 0) {
+        wc[threadIdx.x >> 6] = __popcll(mask);
+        if (index < nPix) masks[index >> 6] = mask;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         blockCounts[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
@@ -65,11 +71,11 @@ valid_count_kernel(const float4 *__restrict__ vert, int nPix, int *__restrict__ 
 // every workgroup sums the counts of the workgroups before it (a few KB, integer sums: order-free) instead of waiting for a scan
 // kernel of its own -- one launch less at the head of every call; the last workgroup leaves the total in *nValid
 __global__ void __launch_bounds__(VC_BLOCK)
-valid_write_kernel(const float4 *__restrict__ vert, int nPix, const int *__restrict__ blockCounts, int *__restrict__ validIdx,
+valid_write_kernel(const unsigned long long *__restrict__ masks, int nPix, const int *__restrict__ blockCounts, int *__restrict__ validIdx,
                    int *__restrict__ nValid) {
     __shared__ int wc[VC_BLOCK / 64];
     __shared__ int ws[VC_BLOCK / 64];
-    vert += (size_t)blockIdx.y * nPix;
+    masks += (size_t)blockIdx.y * ((nPix + 63) / 64);
     blockCounts += (size_t)blockIdx.y * gridDim.x;
     validIdx += (size_t)blockIdx.y * nPix;
     nValid += blockIdx.y;
@@ -79,7 +85,7 @@ valid_write_kernel(const float4 *__restrict__ vert, int nPix, const int *__restr
     for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = before;
     const int index = blockIdx.x * VC_BLOCK + threadIdx.x;
-    const bool v = index < nPix && vert[index].w > 0;
+    const bool v = index < nPix && ((masks[index >> 6] >> (index & 63)) & 1ull);
     int total;
     const int slot = compact_slot<VC_BLOCK>(v, wc, total);      // (synchronises the workgroup)
     const int off = ws[0] + ws[1] + ws[2] + ws[3];
@@ -87,11 +93,12 @@ valid_write_kernel(const float4 *__restrict__ vert, int nPix, const int *__restr
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *nValid = off + total;
 }
 
-// d_work: [frames][ceil(nPix/256)] ints of scratch; d_validIdx: [frames][nPix]; d_nValid: [frames]
+// d_work: valid_pixel_work_ints(nPix, frames) ints of scratch; d_validIdx: [frames][nPix]; d_nValid: [frames]
 int gn_valid_pixels(const float *d_vert, int nPix, int nFrames, int *d_work, int *d_validIdx, int *d_nValid, hipStream_t st) {
     const int nb = (nPix + VC_BLOCK - 1) / VC_BLOCK;
-    hipLaunchKernelGGL(valid_count_kernel, dim3(nb, nFrames), dim3(VC_BLOCK), 0, st, (const float4 *)d_vert, nPix, d_work, (int *)nullptr);
-    hipLaunchKernelGGL(valid_write_kernel, dim3(nb, nFrames), dim3(VC_BLOCK), 0, st, (const float4 *)d_vert, nPix, d_work, d_validIdx, d_nValid);
+    unsigned long long *masks = valid_pixel_masks(d_work, nPix, nFrames);
+    hipLaunchKernelGGL(valid_count_kernel, dim3(nb, nFrames), dim3(VC_BLOCK), 0, st, (const float4 *)d_vert, nPix, d_work, (int *)nullptr, masks);
+    hipLaunchKernelGGL(valid_write_kernel, dim3(nb, nFrames), dim3(VC_BLOCK), 0, st, (const unsigned long long *)masks, nPix, d_work, d_validIdx, d_nValid);
     DARTK_HIP(hipGetLastError());
     return DARTK_OK;
 }
@@ -800,9 +807,10 @@ static int optimize_pose_chunk(Model *mod, int nf, const float *d_vert, const fl
     if (rc) return rc;
     float *slabsA = ws->partials, *slabsB = slabsA + nf * slabA, *slabsC = slabsB + nf * slabB;
     const int nVcBlocks = (nPix + VC_BLOCK - 1) / VC_BLOCK;
-    rc = ensure_valid_idx(ws, (size_t)nf * ((size_t)nPix + nVcBlocks + 1));
+    rc = ensure_valid_idx(ws, (size_t)nf * ((size_t)nPix + 1) + valid_pixel_work_ints(nPix, nf));
     if (rc) return rc;
-    int *validIdx = ws->validIdx, *vcWork = validIdx + (size_t)nf * nPix, *d_nValid = vcWork + (size_t)nf * nVcBlocks;
+    int *validIdx = ws->validIdx, *vcWork = validIdx + (size_t)nf * nPix, *d_nValid = vcWork + valid_pixel_work_ints(nPix, nf);
+    (void)nVcBlocks;
 
     // one allocation: [pose records | observation SDFs | distance-transform scratch | prediction maps | T_gc | systems | counters]
     const size_t rec = 24 + 24 * (size_t)m0.nFrames + (size_t)(m0.nJoints > 0 ? m0.nJoints : 1);
@@ -812,7 +820,7 @@ static int optimize_pose_chunk(Model *mod, int nf, const float *d_vert, const fl
     const size_t o_pose = take(sizeof(float) * rec * nf);
     const size_t o_obs = take(sizeof(float) * mod->obsVoxels * nf * (useB ? 1 : 0));
     const size_t o_tmp = take(sizeof(float) * mod->obsVoxels * nf * (useB ? 1 : 0));
-    const size_t o_pred = take(sizeof(float) * 4 * (size_t)nPred * nf);
+    const size_t o_pred = take(256);        // (the batch returns no prediction maps: the replay keeps each pixel in registers)
     const size_t o_tgc = take(sizeof(float) * 12 * nf);
     const size_t o_sys = take(sizeof(float) * (size_t)sysStride * nf);
     const size_t o_cnt = take(sizeof(int) * 2 * (size_t)nf);
@@ -827,7 +835,8 @@ static int optimize_pose_chunk(Model *mod, int nf, const float *d_vert, const fl
     m.T_mc = p; m.T_cm = p + 12; m.T_mf = p + 24; m.T_fm = p + 24 + 12 * m.nFrames; m.joints = p + 24 + 24 * m.nFrames;
     m.poseStride = (int)rec;
     if (useB) { m.obsData = at(o_obs); m.obsStride = (int)mod->obsVoxels; view.dtTmp = at(o_tmp); }
-    float *d_pred = at(o_pred), *d_T_gc = at(o_tgc);
+    float *d_pred = nullptr, *d_T_gc = at(o_tgc);
+    (void)o_pred;
     float *sysA = at(o_sys), *sysB = sysA + S, *sysC = sysB + S;
     int *cntA = reinterpret_cast<int *>((char *)base + o_cnt), *cntB = cntA + 1;
     const size_t traceFloats = useB ? ray_trace_floats(o->predWidth, o->predHeight, m.nSdfs) : 0;
@@ -974,7 +983,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     float *slabsB = ws->partials, *slabsC = slabsB + (size_t)GN_MAX_BLOCKS * S, *slabsA = slabsC + (size_t)GN_MAX_BLOCKS * S;
     int *cntA = ws->counters, *cntB = ws->counters + 1, *d_nValid = ws->counters + 2;
     const int nVcBlocks = (nPix + VC_BLOCK - 1) / VC_BLOCK;
-    rc = ensure_valid_idx(ws, (size_t)nPix + nVcBlocks);
+    rc = ensure_valid_idx(ws, (size_t)nPix + valid_pixel_work_ints(nPix, 1));
     if (rc) return rc;
     int *validIdx = ws->validIdx, *vcOffsets = ws->validIdx + nPix;
     float *d_T_gc = ws->sysScratch + 128;      // camera -> obs-SDF frame, frozen at the start (optimizer.cpp:446-448)
@@ -1044,9 +1053,10 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     hipStream_t stV = unionAB ? st : stA;        // the valid-pixel list is read by the obs->mod tiles, wherever they run
     if (useA && o->numIterations > 0) {
         ProfScope ps(DARTK_PROF_OTHER, stV);
+        unsigned long long *vcMasks = valid_pixel_masks(vcOffsets, nPix, 1);
         hipLaunchKernelGGL(valid_count_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, stV, (const float4 *)d_vert, nPix, vcOffsets,
-                           zeroInCount ? ws->counters : nullptr);
-        hipLaunchKernelGGL(valid_write_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, stV, (const float4 *)d_vert, nPix, vcOffsets, validIdx, d_nValid);
+                           zeroInCount ? ws->counters : nullptr, vcMasks);
+        hipLaunchKernelGGL(valid_write_kernel, dim3(nVcBlocks), dim3(VC_BLOCK), 0, stV, (const unsigned long long *)vcMasks, nPix, vcOffsets, validIdx, d_nValid);
         DARTK_HIP(hipGetLastError());
     }
     const FusedObs2ModArgs fa = {(const float4 *)d_vert, (const float4 *)d_norm, validIdx, d_nValid, o->distThreshold, o->normThreshold,

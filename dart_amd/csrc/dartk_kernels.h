@@ -64,6 +64,15 @@ int gn_launch_cull(float *d_pred, int pw, int ph, const float *d_obs, int ow, in
 // per frame the indices of the pixels with a valid vertex (w > 0), in pixel order: the observation is fixed for a whole
 // optimisation call, so the association kernels of its iterations walk this list instead of the map
 int gn_valid_pixels(const float *d_vert, int nPix, int nFrames, int *d_work, int *d_validIdx, int *d_nValid, hipStream_t st);
+// ints of scratch gn_valid_pixels needs at d_work: per-workgroup counts, then one validity bit per pixel (the second pass reads the
+// bits the first pass left instead of the vertex map again)
+inline size_t valid_pixel_work_ints(int nPix, int nFrames) {
+    return (size_t)nFrames * ((nPix + 255) / 256) + 4 + 2 * (size_t)nFrames * ((nPix + 63) / 64);
+}
+inline unsigned long long *valid_pixel_masks(int *d_work, int nPix, int nFrames) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_work + (size_t)nFrames * ((nPix + 255) / 256));
+    return reinterpret_cast<unsigned long long *>((a + 7) & ~(uintptr_t)7);
+}
 int gn_obs_sdf_build(const float *d_vert, int width, int height, Model *mod, float focalLength, hipStream_t st,
                      float *d_T_gc_out = nullptr /* optional: receives the camera->model transform the splat was made with */);
 int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int width, int height, int modelNum, const ModelView &m,

@@ -482,7 +482,7 @@ __device__ __forceinline__ void ne_mod2obs_body(const float4 *__restrict__ pred,
     numPredictions += (size_t)by * fb.counts;
     if (REPLAY) {       // the frame's slice of the trace buffer (fb.trace floats apart) and of the prediction maps
         ra.trace += (size_t)by * (fb.trace / 2);
-        ra.predOut += (size_t)by * fb.pred;
+        if (ra.predOut) ra.predOut += (size_t)by * fb.pred;
         if (ra.tables) ra.tables += (size_t)by * ra.tablesStride;
     }
     // hit-list form (batches): `pred` holds the frame's hits back to back, nItems[frame] of them (raycast_replay_multi_rows_kernel)
@@ -508,7 +508,7 @@ __device__ __forceinline__ void ne_mod2obs_body(const float4 *__restrict__ pred,
     const int nT = 12 * m.nFrames, nTab = (REPLAY && ra.tables) ? 28 * m.nSdfs + 1 : 0;
     const bool batched = nT <= QS * NE_BLOCK && nTab <= QS * NE_BLOCK;
     float4 pcFirst = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (REPLAY && bx * NE_BLOCK + (int)threadIdx.x < nPix) pcFirst = ra.predOut[bx * NE_BLOCK + threadIdx.x];
+    if (REPLAY && ra.predOut && bx * NE_BLOCK + (int)threadIdx.x < nPix) pcFirst = ra.predOut[bx * NE_BLOCK + threadIdx.x];
     // the label -> frame -> dependency-mask chain of a contributing pixel is served from LDS
     for (int i = threadIdx.x; i < 2 * m.nFrames + m.nSdfs; i += NE_BLOCK)
         sDep[i] = i < 2 * m.nFrames ? reinterpret_cast<const unsigned *>(m.depMask)[i] : (unsigned)m.sdfFrame[i - 2 * m.nFrames];
@@ -563,14 +563,15 @@ __device__ __forceinline__ void ne_mod2obs_body(const float4 *__restrict__ pred,
         if (index < nPix) {
             float4 pc;
             if (REPLAY) {       // the pixel's prediction is formed here from the per-SDF traces and kept for the caller
-                pc = tile == (int)bx ? pcFirst : ra.predOut[index];
+                // (no map: model 0 of a loop that returns no prediction -- the replay starts every pixel from "no hit" anyway)
+                pc = (tile == (int)bx || !ra.predOut) ? pcFirst : ra.predOut[index];
                 M2O_STAMP(2);
                 if (ra.modelNum == 0) { pc.z = 0; pc.w = -1; }
                 float closestT = 10000;
                 replay_pixel<24>(pc, closestT, index % ra.width, index / ra.width, m.nSdfs, sR, ra.modelNum, 0, m.nSdfs, sRT, ra.trace,
                              ra.flx, ra.fly, ra.ppx, ra.ppy);
                 M2O_STAMP(3);
-                ra.predOut[index] = pc;
+                if (ra.predOut) ra.predOut[index] = pc;
             } else {
                 pc = pred[index];
             }

@@ -541,11 +541,12 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     int *d_validIdx = nullptr, *d_nValid = nullptr;
     if (useA && o->numIterations > 0) {
         const int nb = (nPix + 255) / 256;
-        rc = ensure_valid_idx(ws, (size_t)nFrames * ((size_t)nPix + nb + 1));
+        rc = ensure_valid_idx(ws, (size_t)nFrames * ((size_t)nPix + 1) + valid_pixel_work_ints(nPix, nFrames));
         if (rc) return rc;
         d_validIdx = ws->validIdx;
         int *d_work = d_validIdx + (size_t)nFrames * nPix;
-        d_nValid = d_work + (size_t)nFrames * nb;
+        d_nValid = d_work + valid_pixel_work_ints(nPix, nFrames);
+        (void)nb;
         ProfScope ps(DARTK_PROF_OTHER, st);
         rc = gn_valid_pixels(d_vert, nPix, nFrames, d_work, d_validIdx, d_nValid, st);
         if (rc) return rc;

@@ -6,7 +6,7 @@
 set -e
 TAG=$1
 O=gpurun_out/final
-one() { ls $O/$1/*/*_$2.csv | tail -1; }
+one() { ls -t $O/$1/*/*_$2.csv | head -1; }      # the newest: gpurun_out/ keeps the files of earlier runs
 python3 tools/prof_summary.py "$(one stats kernel_trace)" > profiles/${TAG}_kernel_stats.txt
 cp "$(one stats kernel_stats)" profiles/${TAG}_rocprofv3_kernel_stats.csv
 python3 tools/kernel_durations.py $O/stats profiles/kernel_durations.json > /dev/null
@@ -17,3 +17,6 @@ python3 tools/prof_summary.py "$(one statsP kernel_trace)" > profiles/${TAG}_ker
 python3 tools/kernel_durations.py $O/statsP profiles/kernel_durations_pose_batch.json > /dev/null
 python3 tools/pmc_summary.py --largest "$(one fetchP counter_collection)" "$(one writeP counter_collection)" profiles/pmc_traffic_pose_batch.json > profiles/${TAG}_pmc_hbm_traffic_pose_batch.txt
 echo "profiles/${TAG}_* written"
+for f in write_size_terms valu_lanes timeline_multi; do
+  if [ -f $O/$f.txt ]; then grep -v "rocprofv3\]\|amdgpu.ids" $O/$f.txt > profiles/${TAG}_$f.txt; fi
+done

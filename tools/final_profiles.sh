@@ -21,4 +21,10 @@ timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write5 
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/statsP -- $CMDP > $O/statsP.log 2>&1
 timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetchP -- $CMDP > $O/fetchP.log 2>&1
 timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/writeP -- $CMDP > $O/writeP.log 2>&1
-echo profiles done
+echo profiles done; set +e
+# extras of round 3: WRITE_SIZE of the term-kernel instantiations (scratch check), VALU lane fraction before / after, the config-5
+# single-frame iteration's timeline and host enqueue time
+bash tools/write_size_terms.sh > $O/write_size_terms.txt 2>&1
+bash tools/pmc_valu_lanes.sh > $O/valu_lanes.txt 2>&1
+bash tools/timeline_multi.sh > $O/timeline_multi.txt 2>&1
+echo extras done

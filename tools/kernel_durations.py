@@ -19,7 +19,8 @@ def short(name):
 
 
 def main():
-    files = sorted(glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True))
+    import os
+    files = sorted(glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True), key=os.path.getmtime)     # the newest run last
     if not files:
         raise SystemExit("no *_kernel_trace.csv under %s" % sys.argv[1])
     d = defaultdict(list)
