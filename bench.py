@@ -730,7 +730,7 @@ def main():
                 for m in range(2):
                     mtr.getPose(m).setTransformCameraToModel(mT0[k, m])
                 mtr.getPose(0).getReducedArticulation()[:] = ma0[k]
-                mtr.optimizePosesDevice(mvert[k], mnorm[k])
+                mtr.optimizePosesDevice(mvert[k], mnorm[k], readback=False)     # poses stay on the device between frames
             torch.cuda.synchronize()
             single_its = n_s * m_iters / (time.perf_counter() - ts0)
             # ---- roofline of this leg: HIP-event durations of one batch step with the three chains on ONE stream (side by side

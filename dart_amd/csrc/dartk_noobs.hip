@@ -630,7 +630,9 @@ __device__ __forceinline__ void noobs_terms_body(const NoObsProblem *__restrict_
                         const f3 cdf = se3_apply_w(dfm + 12 * dstFrame, pdm.x, pdm.y, pdm.z, 1.0f);
                         const f3 cg = grid_coords(s, cdf);
                         if (in_bounds_grad_interp(s, cg)) {
-                            float err = sdf_value<CNT_PRIOR>(md.grids, s, cg) * s.res;
+                            // (the reference interpolates the SDF again here, contact_prior.cpp:62: same SDF, same coordinates -- the
+                            // value the search above found; reusing it drops one of the ~5 trilinear lookups a prior costs)
+                            float err = minV * s.res;
                             if (!(fabsf(err) > pr.contactThreshold)) {
                                 if ((double)fabsf(err) < 1e-4) E = 0.0f;       // :70-73
                                 else {

@@ -83,6 +83,16 @@ class DeviceModel:
         return T_mc, T_mf, T_fm, joints[:self.n_joints]
 
 
+def _get_T_mc(self):
+    """camera -> model transform only (one 48-byte copy instead of the four arrays of get_transforms)"""
+    T_mc = np.zeros(12, dtype=F)
+    check(lib().dartk_model_get_transforms(self.handle, _abi.fptr(T_mc), None, None, None))
+    return T_mc
+
+
+DeviceModel.get_T_mc = _get_T_mc
+
+
 def new_pts(n, device="cuda"):
     """Device array of n DataAssociatedPoint records (12 B each)."""
     return torch.empty((max(n, 1), 3), dtype=torch.int32, device=device)

@@ -140,8 +140,10 @@ class Tracker:
         self.models[m].set_pose(p.getTransformCameraToModel(), p.getArticulation())
 
     # ---- Optimizer::optimizePoses (optimizer.cpp:524-781), device-resident (dartk_optimize_poses)
-    def optimizePosesDevice(self, vert, norm, debug=False):
-        """The whole loop in one library call: no host round trip per term or per iteration. Poses come back at the end."""
+    def optimizePosesDevice(self, vert, norm, debug=False, readback=True):
+        """The whole loop in one library call: no host round trip per term or per iteration. Poses come back at the end
+        (readback=False: they stay on the device -- the models' device poses and the returned reduced articulations hold the
+        result -- and the call does not wait for the stream; a caller that tracks frame after frame reads them when it needs them)."""
         import ctypes as C
         from . import _abi
         from ._abi import check, lib
@@ -207,8 +209,11 @@ class Tracker:
         else:
             check(lib().dartk_optimize_poses(C.byref(mo), mm, device._ptr(vert), device._ptr(norm), w, h, device._ptr(self.prediction),
                                              device._ptr(info), device._ptr(first), device._stream()))
+        self._red_art_dev = red_art
+        if not readback:
+            return
         for m in range(n):      # the poses live on the device during the loop; mirror them back once
-            T_mc, _, _, _ = self.models[m].get_transforms()
+            T_mc = self.models[m].get_T_mc()
             p = self.poses[m]
             p.setTransformCameraToModel(T_mc)
             ra_n = p.getReducedArticulatedDimensions()
