@@ -176,3 +176,44 @@ def test_device_loop_repeats(gpu):
         for m in range(2):
             assert np.abs(T[m] - runs[0][0][m]).max() < 2e-5      # measured 2e-6 on one stream and on three alike
         assert np.abs(a - runs[0][1]).max() < 1e-4                  # measured 1.6e-5
+
+
+def test_shared_launch_form_equals_three_stream_form(gpu, monkeypatch):
+    """The single-frame device loop runs its terms in shared launches on one stream (union_terms_kernel) when the problem is
+    eligible, else on three streams with one launch per term: the same bodies on the same data, only the number of workgroups
+    per term -- the partition of the fixed-order sums -- differs. Counts must be equal in every iteration, energies and poses
+    agree to rounding; and a call with readback=False leaves the same result on the device as the default call returns."""
+    iters = 6
+    sc, tr, vert, norm = setup(640, 360, iters)
+
+    def run_once(**kw):
+        for m, (T, a) in enumerate(sc.init):
+            tr.getPose(m).setTransformCameraToModel(T)
+            tr.getPose(m).getReducedArticulation()[:] = a
+        tr.optimizePosesDevice(vert, norm, debug=True, **kw)
+        pose = [(tr.getPose(m).getTransformCameraToModel().copy(), tr.getPose(m).getReducedArticulation().copy()) for m in range(2)]
+        return pose, tr.iteration_summaries.copy()
+
+    pu, iu = run_once()
+    monkeypatch.setenv("DARTK_MULTI_NO_UNION", "1")
+    ps, is_ = run_once()
+    monkeypatch.delenv("DARTK_MULTI_NO_UNION")
+    assert np.array_equal(iu[:, :, 3:5], is_[:, :, 3:5]) and iu[:, :, 3].min() > 100
+    assert np.all(np.abs(iu[:, :, :3] - is_[:, :, :3]) <= 2e-4 * np.abs(is_[:, :, :3]) + 1e-7)       # (later iterations start from poses that differ by rounding)
+    assert np.all(np.abs(iu[0, :, :3] - is_[0, :, :3]) <= 2e-6 * np.abs(is_[0, :, :3]) + 1e-9)
+    for m in range(2):
+        dt, dr = pose_diff(pu[m][0], ps[m][0])
+        # (the box's rotation is weakly observed: rounding-sized differences of the sums grow to a few 1e-4 rad in six iterations)
+        assert dt < 1e-5 and dr < 1e-3 and (len(pu[m][1]) == 0 or np.abs(pu[m][1] - ps[m][1]).max() < 1e-3), (m, dt, dr)
+    # poses left on the device by a call that does not read back
+    for m, (T, a) in enumerate(sc.init):
+        tr.getPose(m).setTransformCameraToModel(T)
+        tr.getPose(m).getReducedArticulation()[:] = a
+    tr.optimizePosesDevice(vert, norm, readback=False)
+    torch.cuda.synchronize()
+    for m in range(2):      # (to rounding: the association lists are appended in a different order run to run)
+        dt, dr = pose_diff(tr.models[m].get_T_mc(), pu[m][0])
+        assert dt < 1e-5 and dr < 1e-3, (m, dt, dr)
+        n_red = len(pu[m][1])
+        if n_red:
+            assert np.abs(tr._red_art_dev[m].cpu().numpy()[:n_red] - pu[m][1]).max() < 1e-3
