@@ -454,6 +454,9 @@ struct ReplayArgs {            // REPLAY variant: the prediction is formed in th
     // the iteration left them (replay_tables_to_global): one coalesced load instead of recomputing them in every workgroup
     const float *tables;
     int tablesStride;          // floats between two frames' tables (a batch), else 0
+    // a batch: a workgroup walks several tiles (the staging of its prologue paid once) yet leaves ONE partial system per TILE, at
+    // the tile's index -- the slabs, hence every sum, are those of a launch with one workgroup per tile
+    int slabPerTile;
 };
 
 // a batch's replay tables: one workgroup per frame leaves what replay_tables_to_global computes for the frame's pose
@@ -613,8 +616,12 @@ __device__ __forceinline__ void ne_mod2obs_body(const float4 *__restrict__ pred,
         if (nActive) acc.accumulate(rows, ld, nActive);
         myCount += nActive;
         __syncthreads();
+        if (REPLAY && ra.slabPerTile) {
+            acc.store(slabs + ((size_t)by * nTiles + tile) * sys_size(d), sys_size(d));
+            acc.init(d, false);
+        }
     }
-    acc.store(slabs + ((size_t)by * gx + bx) * sys_size(d), sys_size(d));
+    if (!(REPLAY && ra.slabPerTile)) acc.store(slabs + ((size_t)by * gx + bx) * sys_size(d), sys_size(d));
     if (threadIdx.x == 0 && myCount) atomicAdd(numPredictions, myCount);
 #ifdef DARTK_STAMPS
     M2O_STAMP(7);
@@ -892,8 +899,14 @@ int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int
                            d_batchTables, tabStride);
         d_tables = d_batchTables;
     }
+    // a batch whose frames have one slab per tile: four tiles per workgroup
+    const int nTilesM2o = (nPix + NE_BLOCK - 1) / NE_BLOCK;
+    static const char *envTpw = getenv("DARTK_M2O_BATCH_TILES");       // diagnostic override
+    const int tpwB = envTpw && atoi(envTpw) > 0 ? atoi(envTpw) : 4;
+    const bool perTile = fb.n > 1 && nBlocks == nTilesM2o && tpwB > 1;
+    const int gridX = perTile ? (nTilesM2o + tpwB - 1) / tpwB : nBlocks;
     const ReplayArgs ra = {flx, fly, ppx, ppy, width, modelNum, (const float2 *)ws->rayBuf, (float4 *)d_prediction, d_tables,
-                           fb.n > 1 ? tabStride : 0};
+                           fb.n > 1 ? tabStride : 0, perTile ? 1 : 0};
     const int tgcStride = fb.n > 1 ? fb.tab : 0;
     ProfScope ps(DARTK_PROF_NE_MOD2OBS, st);
 #define DARTK_LAUNCH_RM2O(PPT_)                                                                                 \
@@ -901,7 +914,7 @@ int gn_launch_raycast_ne_mod2obs(float flx, float fly, float ppx, float ppy, int
         auto kfn = ne_mod2obs_kernel<PPT_, 0, false, true>;                                                     \
         if (ldsBytes > 64 * 1024)                                                                               \
             DARTK_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
-        hipLaunchKernelGGL(kfn, dim3(nBlocks, fb.n), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_prediction, nPix, m.modelId, m, d_T_gc, 0.f, \
+        hipLaunchKernelGGL(kfn, dim3(gridX, fb.n), dim3(NE_BLOCK), ldsBytes, st, (const float4 *)d_prediction, nPix, m.modelId, m, d_T_gc, 0.f, \
                            d, nullptr, nullptr, slabs, d_num, ra, fb, tgcStride, (const int *)nullptr); \
     } while (0)
     if (S <= 3 * NE_BLOCK) DARTK_LAUNCH_RM2O(3);
