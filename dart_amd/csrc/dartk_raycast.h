@@ -221,8 +221,11 @@ __device__ __forceinline__ void trace_one_ray(const ModelView &m, int s, int x, 
         int steps = 0;
 #endif
         const float minStep = res / 10;
+        // The reference samples the entry point twice (raycast.cu:171-173 before the loop, :180-183 in its first turn): the same point, the
+        // same value, a turn that can find no crossing. The second sample is not taken here -- one dependent lookup less per
+        // marched ray, a tenth of an average march.
+        float sdfVal = sdfValPrev;
         while (t0 < t1 && t0 < 10000.0f) {      // 10000 = the reference's initial closestT
-            const float sdfVal = eval(t0);
             if (sdfValPrev > levelSet && sdfVal <= levelSet) {
                 det = t0;
                 hit = (t0 - tPrev) * (levelSet - sdfValPrev) / (sdfVal - sdfValPrev) + tPrev;
@@ -234,6 +237,8 @@ __device__ __forceinline__ void trace_one_ray(const ModelView &m, int s, int x, 
 #ifdef DARTK_STAMPS
             ++steps;
 #endif
+            if (!(t0 < t1 && t0 < 10000.0f)) break;
+            sdfVal = eval(t0);
         }
 #ifdef DARTK_STAMPS
         atomicMax(&g_rayMaxSteps, steps);
