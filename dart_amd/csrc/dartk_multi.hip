@@ -54,11 +54,13 @@ struct MultiSolveArgs {
 };
 
 // projection of the reduced articulation in ra[] (LDS) to the full joint vector (pose.cpp:66-73, 91-97) and forward
-// kinematics (Tracker::updatePose) of one model; one wave
-__device__ __forceinline__ void project_and_fk(const MultiSolveModel &m, const ModelView &v, const float *ra, float *sT) {
-    const int lane = threadIdx.x;
-    if (lane < v.nJoints) {       // lane f writes joint f and is the lane that reads it back in fk_wave
-        float full;
+// kinematics (Tracker::updatePose) of one model; one wave. `t`: the model's constant joint / frame tables (fk_prefetch), loaded by
+// the caller ahead of the work the new joint values wait for. Joint j belongs to lane j, which is the lane that moves frame j + 1:
+// its value goes into the kinematics in a register, the store to v.joints is for the kernels that follow.
+__device__ __forceinline__ void project_and_fk(const MultiSolveModel &m, const ModelView &v, const float *ra, float *sT, const FkTables &t) {
+    const int lane = threadIdx.x & 63;
+    float full = 0.0f;
+    if (lane < v.nJoints) {
         if (m.redType == 0) full = ra[lane];
         else if (m.redType == 2) full = ra[m.map[lane]];
         else {
@@ -67,26 +69,10 @@ __device__ __forceinline__ void project_and_fk(const MultiSolveModel &m, const M
         }
         v.joints[lane] = full;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    fk_wave(v, 0, sT);
+    fk_wave(v, 0, sT, t, (lane + 1 < v.nFrames) ? full : 0.0f);
 }
 
 __device__ __forceinline__ void wave_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-// Optimizer::unpack (optimizer.cpp:50-70) into the model's block: eJ += lam*J^T e; upper J(i,j) += lam*packed[j(j+1)/2+i]
-__device__ __forceinline__ void unpack_block(float *J, int ld, float *eJ, const float *__restrict__ sys, float lam, int dims, int shift) {
-    const int lane = threadIdx.x & 63;
-    const int d = dims - shift;             // shift = 6: articulation-only system into the bottom-right block
-    for (int idx = lane; idx < d * d; idx += 64) {
-        const int i = idx / d, j = idx - i * d;
-        if (j < i) continue;
-        float t = 0.0f;
-        t += lam * sys[d + ((j * (j + 1)) >> 1) + i];
-        J[(shift + i) * ld + shift + j] += t;
-    }
-    for (int i = lane; i < d; i += 64) { float t = 0.0f; t += lam * sys[i]; eJ[shift + i] += t; }
-    wave_sync_lds();
-}
 
 // ContactPrior::computeContribution (contact_prior.cpp:8-205) and updatePriorParams (:207-221) of one prior, by ONE lane: the
 // tracking loop carries a handful of priors (hand-object contacts), so they are evaluated in the solve kernel against the
@@ -186,11 +172,12 @@ __device__ __noinline__ void multi_eval_contact_prior(const MultiSolveArgs &a, i
 
 // iteration: >= 0 the Gauss-Newton iteration; -1 / -2 import / export of a batch's poses; -3 the iteration whose number the
 // previous solve left in *a.itCounter (the replayed launches of a captured iteration all carry the same argument)
-__global__ void __launch_bounds__(64)
-multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration) {
+__global__ void __launch_bounds__(64 * DARTK_MAX_MODELS)
+multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration, int fkFloats) {
     extern __shared__ float lds[];
     const MultiSolveArgs &a = *ap;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;              // wave w assembles and updates model w; wave 0 solves
     const int frame = blockIdx.x;                   // frame of a batch (0 otherwise)
     if (iteration == -3) iteration = *a.itCounter;
     const size_t so = (size_t)frame * a.fb.sys, co = (size_t)frame * a.fb.counts;
@@ -198,142 +185,191 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration) {
     const int ldU = (D + 1) | 1;
     float *U = lds;                     // [D][ldU] upper triangle of the global system
     float *bv = U + D * ldU;            // [D]
-    float *J = bv + D;                  // one model's block [dims][ldU]
-    float *eJ = J + D * ldU;            // [D]
-    float *ra = eJ + D;                 // reduced articulation of the model being updated [<= 64]
-    float *sT = ra + 64;                // forward-kinematics scratch
+    float *J = bv + D;                  // a prior's Jacobian row over the global unknowns [D] (wave 0)
+    float *eJ = J + D * ldU;            // its scalars
+    float *ra = eJ + D + (size_t)wave * (64 + fkFloats);   // per wave: reduced articulation of its model [<= 64]
+    float *sT = ra + 64;                // per wave: forward-kinematics scratch [fkFloats]
+    const bool mine = wave < a.nModels;
+    const MultiSolveModel &m = a.m[mine ? wave : 0];
+    ModelView v = m.v;
+    select_frame(v, frame);
     if (iteration < 0) {        // batch only: import (-1) / export (-2) the caller's poses
-        for (int mi = 0; mi < a.nModels; ++mi) {
-            const MultiSolveModel &m = a.m[mi];
-            ModelView v = m.v;
-            select_frame(v, frame);
-            float *T_io = a.T_mcs + ((size_t)frame * a.nModels + mi) * 12;
-            if (iteration == -2) {
-                if (lane < 12) T_io[lane] = v.T_mc[lane];
-                continue;
-            }
-            if (lane == 0) {
-                float T[12], Tinv[12];
-                for (int i = 0; i < 12; ++i) T[i] = T_io[i];
-                se3_invert(T, Tinv);
-                for (int i = 0; i < 12; ++i) { v.T_mc[i] = T[i]; v.T_cm[i] = Tinv[i]; }
-            }
-            if (lane < m.redArt) ra[lane] = m.redArtPtr[(size_t)frame * a.redStride + lane];
-            wave_sync_lds();
-            project_and_fk(m, v, ra, sT);
-            wave_sync_lds();
+        if (!mine) return;
+        float *T_io = a.T_mcs + ((size_t)frame * a.nModels + wave) * 12;
+        if (iteration == -2) {
+            if (lane < 12) T_io[lane] = v.T_mc[lane];
+            return;
         }
+        const FkTables tab = fk_prefetch(v);
+        if (lane == 0) {
+            float T[12], Tinv[12];
+            for (int i = 0; i < 12; ++i) T[i] = T_io[i];
+            se3_invert(T, Tinv);
+            for (int i = 0; i < 12; ++i) { v.T_mc[i] = T[i]; v.T_cm[i] = Tinv[i]; }
+        }
+        if (lane < m.redArt) ra[lane] = m.redArtPtr[(size_t)frame * a.redStride + lane];
+        wave_sync_lds();
+        project_and_fk(m, v, ra, sT, tab);
         return;
     }
-    for (int i = lane; i < D * ldU; i += 64) U[i] = 0.0f;
-    for (int i = lane; i < D; i += 64) bv[i] = 0.0f;
-    wave_sync_lds();
-    for (int mi = 0; mi < a.nModels; ++mi) {
-        const MultiSolveModel &m = a.m[mi];
-        const int dims = m.dims, off = m.off;
-        for (int i = lane; i < dims * ldU; i += 64) J[i] = 0.0f;
-        for (int i = lane; i < dims; i += 64) eJ[i] = 0.0f;
-        wave_sync_lds();
-        float eA = 0.0f, eB = 0.0f, eI = 0.0f;
-        if (m.sysA) { unpack_block(J, ldU, eJ, m.sysA + so, a.lambdaA, dims, 0); eA = a.lambdaA * m.sysA[so + sys_size(dims) - 1]; }
-        if (m.sysB) { unpack_block(J, ldU, eJ, m.sysB + so, a.lambdaB, dims, 0); eB = a.lambdaB * m.sysB[so + sys_size(dims) - 1]; }
-        if (m.sysC) { unpack_block(J, ldU, eJ, m.sysC + so, m.lamSelf, dims, 6); eI = m.lamSelf * m.sysC[so + sys_size(dims - 6) - 1]; }
-        for (int d = 0; d < a.nModels; ++d)
-            if (m.sysI[d]) { unpack_block(J, ldU, eJ, m.sysI[d] + so, m.lamI[d], dims, 0); eI = m.lamI[d] * m.sysI[d][so + sys_size(dims) - 1]; }
+#ifdef DARTK_STAMPS
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // what the update at the end needs and the solution does not change: in flight from here on
+    const FkTables tab = fk_prefetch(v);
+    float T_old[12];
+    if (mine && lane == 0)
+        for (int i = 0; i < 12; ++i) T_old[i] = v.T_mc[i];
+    float redOld = 0.0f, redLo = 0.0f, redHi = 0.0f;
+    if (mine && lane < m.redArt) { redOld = m.redArtPtr[(size_t)frame * a.redStride + lane]; redLo = m.redMin[lane]; redHi = m.redMax[lane]; }
+    for (int i = threadIdx.x; i < D * ldU; i += blockDim.x) U[i] = 0.0f;
+    if (threadIdx.x < D) bv[threadIdx.x] = 0.0f;
+    __syncthreads();
+    // Assembly of the models' diagonal blocks (optimizer.cpp:640-713). The reference unpacks term after term into the model's JTJ /
+    // eJ (Optimizer::unpack, :50-70), adds the regularisation and copies the upper triangle into the global system. Here a lane owns
+    // an entry and adds the terms' values in that order in a register -- the same sums -- so that every load of every term is in
+    // flight at once instead of one dependent round trip per term, and the models' blocks are assembled side by side, a wave each
+    // (the kernel's duration is its chain of latencies).
+    if (mine) {
+        const int dims = m.dims, off = m.off, dC = dims - 6;
+        constexpr int kTerms = 3 + DARTK_MAX_MODELS;
+        const float *sys[kTerms];
+        float lam[kTerms];
+        sys[0] = m.sysA ? m.sysA + so : nullptr; lam[0] = a.lambdaA;
+        sys[1] = m.sysB ? m.sysB + so : nullptr; lam[1] = a.lambdaB;
+        sys[2] = m.sysC ? m.sysC + so : nullptr; lam[2] = m.lamSelf;          // articulation-only system: the bottom-right block
+#pragma unroll
+        for (int d = 0; d < DARTK_MAX_MODELS; ++d) {
+            const bool on = d < a.nModels && m.sysI[d];
+            sys[3 + d] = on ? m.sysI[d] + so : nullptr; lam[3 + d] = m.lamI[d];
+        }
+        const int S = sys_size(dims);
         if (a.iterInfo && lane == 0) {      // e is assigned per term, the last one stays (SURVEY A-8)
-            float *r = a.iterInfo + (size_t)frame * a.infoStride + ((size_t)iteration * a.nModels + mi) * 8;
+            float eA = 0.0f, eB = 0.0f, eI = 0.0f;
+            if (sys[0]) eA = lam[0] * sys[0][S - 1];
+            if (sys[1]) eB = lam[1] * sys[1][S - 1];
+            if (sys[2]) eI = lam[2] * sys[2][sys_size(dC) - 1];
+#pragma unroll
+            for (int d = 0; d < DARTK_MAX_MODELS; ++d) if (sys[3 + d]) eI = lam[3 + d] * sys[3 + d][S - 1];
+            float *r = a.iterInfo + (size_t)frame * a.infoStride + ((size_t)iteration * a.nModels + wave) * 8;
             r[0] = eA; r[1] = eB; r[2] = eI; r[3] = m.countA ? (float)m.countA[co] : 0.0f; r[4] = m.countB ? (float)m.countB[co] : 0.0f;
             r[5] = r[6] = r[7] = 0.0f;
         }
-        // regularisation, LM scaling (optimizer.cpp:695-700), then the upper triangle goes into the global system (:707-713)
-        for (int i = lane; i < dims; i += 64) {
-            float v = J[i * ldU + i];
-            v += m.reg * 1.0f;
-            v += m.regScaled * v;
-            J[i * ldU + i] = v;
-        }
-        wave_sync_lds();
-        for (int idx = lane; idx < dims * dims; idx += 64) {
-            const int i = idx / dims, j = idx - i * dims;
-            if (j < i) continue;
-            float v = J[i * ldU + j];
-            if (m.damping) v += m.damping[idx];                     // JTJ += *dampingMatrices[m]  (:702-703)
-            U[(off + i) * ldU + off + j] = v;
-        }
-        for (int i = lane; i < dims; i += 64) bv[off + i] = eJ[i];
-        wave_sync_lds();
-    }
-    // priors[p]->computeContribution into the assembled system, in list order (:727-730): J^T e += (w err) J, upper J^T J +=
-    // (w J_r) J_c over the source block, the destination block and their cross block (contact_prior.cpp:128-157,187-204)
-    for (int p = 0; p < a.nPriors; ++p) {
-        float *L = J, *sc = eJ;
-        if (lane == 0) multi_eval_contact_prior(a, frame, a.priors + p, L, sc);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (sc[2] != 0.0f) {
-            const float fold = sc[0], w = sc[1];
-            for (int idx = lane; idx < D * D; idx += 64) {
-                const int r = idx / D, c = idx - r * D;
-                if (c < r) continue;
-                const float val = (w * L[r]) * L[c];
-                if (val != 0.0f) U[r * ldU + c] += val;
+        // entries [0, dims*dims): the block's (i, j), upper triangle only; [dims*dims, dims*dims + dims): J^T e
+        for (int idx = lane; idx < dims * dims + dims; idx += 64) {
+            const bool rhs = idx >= dims * dims;
+            const int i = rhs ? idx - dims * dims : idx / dims, j = rhs ? 0 : idx - i * dims;
+            if (!rhs && j < i) continue;
+            float val[kTerms];
+#pragma unroll
+            for (int t = 0; t < kTerms; ++t) {
+                val[t] = 0.0f;
+                if (!sys[t]) continue;
+                if (t == 2) {
+                    if (i < 6 || (!rhs && j < 6)) continue;
+                    val[t] = rhs ? sys[t][i - 6] : sys[t][dC + (((j - 6) * (j - 5)) >> 1) + (i - 6)];
+                } else
+                    val[t] = rhs ? sys[t][i] : sys[t][dims + ((j * (j + 1)) >> 1) + i];
             }
-            for (int i = lane; i < D; i += 64) bv[i] += fold * L[i];
+            float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < kTerms; ++t) {
+                if (!sys[t] || (t == 2 && (i < 6 || (!rhs && j < 6)))) continue;
+                float tt = 0.0f;
+                tt += lam[t] * val[t];
+                acc += tt;
+            }
+            if (rhs) { bv[off + i] = acc; continue; }
+            if (i == j) {       // regularisation, LM scaling (optimizer.cpp:695-700)
+                acc += m.reg * 1.0f;
+                acc += m.regScaled * acc;
+            }
+            if (m.damping) acc += m.damping[idx];                           // JTJ += *dampingMatrices[m]  (:702-703)
+            U[(off + i) * ldU + off + j] = acc;
         }
-        wave_sync_lds();
     }
-    if (a.firstSystem && iteration == 0 && frame == 0) {
-        for (int idx = lane; idx < D * D; idx += 64) a.firstSystem[idx] = U[(idx / D) * ldU + (idx % D)];
-        for (int i = lane; i < D; i += 64) a.firstSystem[D * D + i] = bv[i];
-    }
-    // paramUpdate = -U^-1 JTe by back substitution on the upper triangle (Eigen triangularView<Upper>().solve, :732:
-    // columns last to first, a column is skipped when its rhs entry is exactly 0)
-    float x = lane < D ? bv[lane] : 0.0f;       // D <= 64: lane r holds x[r]
-    for (int i = D - 1; i >= 0; --i) {
-        float xi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i));
-        if (xi != 0.0f) {
-            xi = xi / U[i * ldU + i];
-            if (lane == i) x = xi;
-            if (lane < i) {
-                const float u = U[lane * ldU + i];
-                if (u != 0.0f) x -= xi * u;
+    __syncthreads();
+#ifdef DARTK_STAMPS
+    const unsigned long long stamp1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (wave == 0) {
+        // priors[p]->computeContribution into the assembled system, in list order (:727-730): J^T e += (w err) J, upper J^T J +=
+        // (w J_r) J_c over the source block, the destination block and their cross block (contact_prior.cpp:128-157,187-204)
+        for (int p = 0; p < a.nPriors; ++p) {
+            float *L = J, *sc = eJ;
+            if (lane == 0) multi_eval_contact_prior(a, frame, a.priors + p, L, sc);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (sc[2] != 0.0f) {
+                const float fold = sc[0], w = sc[1];
+                for (int idx = lane; idx < D * D; idx += 64) {
+                    const int r = idx / D, c = idx - r * D;
+                    if (c < r) continue;
+                    const float val = (w * L[r]) * L[c];
+                    if (val != 0.0f) U[r * ldU + c] += val;
+                }
+                for (int i = lane; i < D; i += 64) bv[i] += fold * L[i];
+            }
+            wave_sync_lds();
+        }
+        if (a.firstSystem && iteration == 0 && frame == 0) {
+            for (int idx = lane; idx < D * D; idx += 64) a.firstSystem[idx] = U[(idx / D) * ldU + (idx % D)];
+            for (int i = lane; i < D; i += 64) a.firstSystem[D * D + i] = bv[i];
+        }
+        // paramUpdate = -U^-1 JTe by back substitution on the upper triangle (Eigen triangularView<Upper>().solve, :732:
+        // columns last to first, a column is skipped when its rhs entry is exactly 0)
+        float x = lane < D ? bv[lane] : 0.0f;       // D <= 64: lane r holds x[r]
+        for (int i = D - 1; i >= 0; --i) {
+            float xi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i));
+            if (xi != 0.0f) {
+                xi = xi / U[i * ldU + i];
+                if (lane == i) x = xi;
+                if (lane < i) {
+                    const float u = U[lane * ldU + i];
+                    if (u != 0.0f) x -= xi * u;
+                }
             }
         }
+        x = -x;
+        if (lane < D) bv[lane] = x;
     }
-    x = -x;
-    if (lane < D) bv[lane] = x;
-    wave_sync_lds();
-    // pose updates (:734-755), projection to the full joint vector, forward kinematics (Tracker::updatePose)
-    for (int mi = 0; mi < a.nModels; ++mi) {
-        const MultiSolveModel &m = a.m[mi];
+    __syncthreads();
+#ifdef DARTK_STAMPS
+    const unsigned long long stamp2 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // pose updates (:734-755), projection to the full joint vector, forward kinematics (Tracker::updatePose): a wave per model
+    if (mine) {
         const int off = m.off;
-        ModelView v = m.v;
-        select_frame(v, frame);
         if (lane == 0) {
-            float t6[6], dT[12], T[12], Tn[12], Tinv[12];
+            float t6[6], dT[12], Tn[12], Tinv[12];
             for (int i = 0; i < 6; ++i) t6[i] = bv[off + i];
             se3_exp(t6, dT);
-            for (int i = 0; i < 12; ++i) T[i] = v.T_mc[i];
-            se3_mul(dT, T, Tn);
+            se3_mul(dT, T_old, Tn);
             se3_invert(Tn, Tinv);
             for (int i = 0; i < 12; ++i) { v.T_mc[i] = Tn[i]; v.T_cm[i] = Tinv[i]; }
         }
         if (lane < m.redArt) {
-            float *rp = m.redArtPtr + (size_t)frame * a.redStride;
-            const float val = rp[lane] + bv[off + 6 + lane];
-            const float c = fminf(fmaxf(m.redMin[lane], val), m.redMax[lane]);
-            rp[lane] = c;
+            const float val = redOld + bv[off + 6 + lane];
+            const float c = fminf(fmaxf(redLo, val), redHi);
+            m.redArtPtr[(size_t)frame * a.redStride + lane] = c;
             ra[lane] = c;
         }
         wave_sync_lds();
-        project_and_fk(m, v, ra, sT);
-        wave_sync_lds();
+        project_and_fk(m, v, ra, sT, tab);
     }
     // this iteration's counts have been read (summaries above, the gated reductions before this launch): ready for the next
-    if (lane < DARTK_MAX_MODELS) {       // (the arrays hold DARTK_MAX_MODELS counters per frame in either form of the loop)
-        if (a.zeroA) a.zeroA[co + lane] = 0;
-        if (a.zeroB) a.zeroB[co + lane] = 0;
+    if (threadIdx.x < DARTK_MAX_MODELS) {       // (the arrays hold DARTK_MAX_MODELS counters per frame in either form of the loop)
+        if (a.zeroA) a.zeroA[co + threadIdx.x] = 0;
+        if (a.zeroB) a.zeroB[co + threadIdx.x] = 0;
     }
-    if (lane == 0 && frame == 0 && a.itCounter) *a.itCounter = iteration + 1;
+    if (threadIdx.x == 0 && frame == 0 && a.itCounter) *a.itCounter = iteration + 1;
+#ifdef DARTK_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long stamp3 = __builtin_amdgcn_s_memrealtime();
+    if (a.iterInfo && threadIdx.x == 0) {      // 10 ns ticks: assembly | priors + back substitution | pose updates + forward kinematics
+        float *r = a.iterInfo + (size_t)frame * a.infoStride + ((size_t)iteration * a.nModels) * 8;
+        r[5] = (float)(stamp1 - stamp0); r[6] = (float)(stamp2 - stamp1); r[7] = (float)(stamp3 - stamp2);
+    }
+#endif
 }
 
 // per-device buffers of the loop (argument block, per-term systems, small tables)
@@ -516,13 +552,14 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     }
 
     const int ldU = (D + 1) | 1;
-    const size_t ldsSolve = sizeof(float) * ((size_t)2 * D * ldU + 2 * D + 64 + 12 * (size_t)maxFrames + 8);
+    const int fkFloats = 12 * maxFrames + 8;          // forward-kinematics scratch of one wave (= model)
+    const size_t ldsSolve = sizeof(float) * ((size_t)2 * D * ldU + 2 * D + (size_t)n * (64 + fkFloats));
     DARTK_REQUIRE(ldsSolve <= 160 * 1024, "LDS requirement exceeds 160 KiB");
     if (ldsSolve > 64 * 1024)
         DARTK_HIP(hipFuncSetAttribute((const void *)multi_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
     BatchScope scope(fb);       // every launcher below covers all frames
     if (batch)                  // import the caller's poses: T_mc, projection of the reduced articulation, forward kinematics
-        hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64), ldsSolve, st, d_args, -1);
+        hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64 * n), ldsSolve, st, d_args, -1, fkFloats);
 
     // association argument block (pose arrays are updated in place, so once per call)
     void *d_assocArgs = nullptr;
@@ -753,7 +790,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         if (rc) return rc;
         {
             ProfScope ps(DARTK_PROF_SOLVE, st);
-            hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64), ldsSolve, st, d_args, it);
+            hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64 * n), ldsSolve, st, d_args, it, fkFloats);
         }
         DARTK_HIP(hipGetLastError());
         return DARTK_OK;
@@ -840,7 +877,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         if (ws->deferReduce) { rc = flush_reduce_jobs(ws, st); if (rc) return rc; }
         {
             ProfScope ps(DARTK_PROF_SOLVE, st);
-            hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64), ldsSolve, st, d_args, solveArg);
+            hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64 * n), ldsSolve, st, d_args, solveArg, fkFloats);
         }
         DARTK_HIP(hipGetLastError());
         if (deferLater && it == 0) {
@@ -863,7 +900,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     }
     ws->deferReduce = false;
     if (batch) {                // export the poses
-        hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64), ldsSolve, st, d_args, -2);
+        hipLaunchKernelGGL(multi_solve_kernel, dim3(nFrames), dim3(64 * n), ldsSolve, st, d_args, -2, fkFloats);
         DARTK_HIP(hipGetLastError());
     }
     return DARTK_OK;
