@@ -32,6 +32,7 @@ struct BatchScope {         // sets the current batch for a scope
 
 // ring of (pinned host, device) argument slots, see dartk_model.hip
 struct ArgSlot { void *d; void *h; int idx, dev; };
+size_t arg_slot_bytes();
 int arg_ring_acquire(size_t bytes, ArgSlot *out);
 int arg_ring_release(const ArgSlot &s, hipStream_t st);
 int ensure_partials(Workspace *w, size_t floats);
@@ -54,7 +55,7 @@ int gn_launch_raycast_replay_at(float flx, float fly, float ppx, float ppy, int 
                                 float *d_prediction, size_t bufOffset, hipStream_t st);
 int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float ppy, int width, int height, int nModels,
                                         Model *const *mods, const size_t *bufOffsets, float *d_prediction, const float *d_obs, int ow,
-                                        int oh, hipStream_t st, int *d_hitCount = nullptr);
+                                        int oh, hipStream_t st, int *d_hitCount = nullptr, const float *d_tables = nullptr);
 // batches: the replay can leave each frame's hits back to back at the start of its map region (d_hitCount[frame * counts stride]
 // of them) instead of the map; gn_ne_mod2obs_any then walks the list (d_nItems = the same counters)
 bool gn_replay_hit_lists(int nModels, Model *const *mods);
@@ -110,7 +111,34 @@ int gn_ne_inter_any(int red, const float *d_sites, int nSites, int fullDims, int
 // body (dartk_ne_bodies.h, the ray-cast trace) on them with its own arguments, as if it had been launched alone with `count`
 // workgroups. The table lives in device memory (written once per call: nothing in it changes between iterations).
 struct MultiArgs;
-enum UnionKind { UK_TRACE = 0, UK_ASSOC = 1, UK_SELF = 2, UK_INTER = 3, UK_M2O = 4, UK_O2M = 5 };
+struct ReplayArgs {            // REPLAY variant: the prediction is formed in the kernel from the ray-cast traces
+    float flx, fly, ppx, ppy;
+    int width, modelNum;       // modelNum: the label's model number (raycast.cu's modelNum argument)
+    const float2 *trace;       // [nSdfs][nPix] {detection t, hit t}
+    float4 *predOut;
+    // optional: this pose's [per-SDF ray transforms (24 nSdfs floats) | tile rectangles (4 nSdfs + 1 ints)] as an earlier kernel of
+    // the iteration left them (replay_tables_to_global): one coalesced load instead of recomputing them in every workgroup
+    const float *tables;
+    int tablesStride;          // floats between two frames' tables (a batch), else 0
+    // a batch: a workgroup walks several tiles (the staging of its prologue paid once) yet leaves ONE partial system per TILE, at
+    // the tile's index -- the slabs, hence every sum, are those of a launch with one workgroup per tile
+    int slabPerTile;
+    // REPLAY == 2 (the multi-model single-frame loop): the pixel's prediction is the closest hit over EVERY model of the call, in
+    // model order (what raycast_replay_multi_kernel leaves in the map), then cullUnobservable; `tables` holds the models' tables
+    // back to back, `trace` is the base of the trace buffer. The per-model part sits in device memory (read through the scalar
+    // cache with a uniform index; by value its indexed arrays would put the whole argument block into scratch).
+    const struct ReplayMulti *multi;
+};
+struct ReplayMulti {
+    int nModels, nSdfsOf[DARTK_MAX_MODELS];
+    unsigned long long traceOff[DARTK_MAX_MODELS];      // each model's slice of the trace buffer (floats)
+    const float4 *obs; int ow, oh;      // the observed vertex map of cullUnobservable (modToObs.cu:682-709)
+    int writesMap;                      // this term's workgroups leave the map in predOut (one of the models' terms does)
+};
+
+
+enum UnionKind { UK_TRACE = 0, UK_ASSOC = 1, UK_SELF = 2, UK_INTER = 3, UK_M2O = 4, UK_O2M = 5,
+                 UK_TABLES = 6 };    // one workgroup: the model's [ray transforms | tile rectangles] of this pose -> slabs (28 nSdfs + 1 words)
 struct UnionSeg {
     int first, count, kind, red;        // red: 0 full pose, 1 linear reduction, 2 parameter map (the body's RED)
     ModelView m, m2;                    // the term's model (the source model of an intersection) / the destination model
@@ -121,6 +149,8 @@ struct UnionSeg {
     const float4 *vert; int nPix; const MultiArgs *assocArgs; int *lastElement; const int *validIdx, *nValid;   // association
     const float4 *pred; int nPred; const float *T_gc; int *numPredictions;            // mod->obs
     const dartk_da_point *pts; float huberDelta; const int *count_;                   // obs->mod (list length on the device)
+    ReplayArgs replay;                  // mod->obs with replay.tables set: the term forms the prediction itself (ne_mod2obs_body, REPLAY == 2)
+    ReplayMulti replayMulti;            // (replay.multi points at this member of the table in device memory)
 };
 static constexpr int kMaxUnionSegs = 16;
 struct UnionTable { int nSeg, pad; UnionSeg seg[kMaxUnionSegs]; };

@@ -161,17 +161,28 @@ raycast_replay_multi_kernel(float flx, float fly, float ppx, float ppy, int widt
 // above costs on a batch is not the pixels but its prologue -- per model a chain of dependent loads (SDF headers, pose,
 // rectangles, transforms) and barriers, paid by every one of the 900 workgroups of a 640x360 frame: 650 us for 64 frames.
 // Here a frame takes a few dozen workgroups and each pays the prologue once.
+// tables (single frame only): the models' [transforms 24 n | rectangles 4 n + 1] of this pose, back to back in model order, as a
+// UK_TABLES workgroup of the launch before left them (replay_tables_to_global) -- the prologue is then one copy, no chain of
+// dependent loads per model. keepXY: x, y of a pixel without a hit stay what the caller's map held (the reference's behaviour).
 __global__ void __launch_bounds__(256)
 raycast_replay_multi_rows_kernel(float flx, float fly, float ppx, float ppy, int width, int height, ReplayMultiArgs a,
                                  const float *__restrict__ rayBuf, float4 *__restrict__ prediction, const float4 *__restrict__ obs, int ow,
-                                 int oh, FrameBatch fb, int *__restrict__ hitCount) {
+                                 int oh, FrameBatch fb, int *__restrict__ hitCount, const float *__restrict__ tables, int keepXY) {
     extern __shared__ float lds[];
     const int frame = blockIdx.y;
     rayBuf += (size_t)frame * fb.trace;
     prediction += (size_t)frame * fb.pred;
     obs += (size_t)frame * fb.vert;
     const int nPix = width * height;
-    {
+    if (tables) {
+        int off = 0;
+        for (int mi = 0; mi < a.n; ++mi) {
+            const int n = a.m[mi].nSdfs, nR = 4 * n + 1;
+            for (int i = threadIdx.x; i < 28 * n + 1; i += blockDim.x) lds[off + i] = (i < nR) ? tables[off + 24 * n + i] : tables[off + i - nR];
+            off += 28 * n + 1;
+        }
+        __syncthreads();
+    } else {
         int off = 0;
         for (int mi = 0; mi < a.n; ++mi) {
             ModelView m = a.m[mi];
@@ -212,6 +223,7 @@ raycast_replay_multi_rows_kernel(float flx, float fly, float ppx, float ppy, int
         // model 0 starts the map. The reference leaves x, y of a pixel without a hit as they were; nothing reads them (every
         // consumer tests z first), and this kernel only ever writes the loop's own scratch map, so they are not fetched
         float4 pr = make_float4(0.f, 0.f, 0.f, -1.f);
+        if (keepXY && inMap) { pr = prediction[index]; pr.z = 0.f; pr.w = -1.f; }
         if (inMap && (x >> 3) >= ux0 && (x >> 3) <= ux1 && (y >> 3) >= uy0 && (y >> 3) <= uy1) {
             int off = 0;
             for (int mi = 0; mi < a.n; ++mi) {
@@ -445,20 +457,6 @@ __device__ unsigned long long g_m2oStamps[1024 * 8];     // per workgroup of the
 #else
 #define M2O_STAMP(i) do { } while (0)
 #endif
-struct ReplayArgs {            // REPLAY variant: the prediction is formed in the kernel from the ray-cast traces
-    float flx, fly, ppx, ppy;
-    int width, modelNum;       // modelNum: the label's model number (raycast.cu's modelNum argument)
-    const float2 *trace;       // [nSdfs][nPix] {detection t, hit t}
-    float4 *predOut;
-    // optional: this pose's [per-SDF ray transforms (24 nSdfs floats) | tile rectangles (4 nSdfs + 1 ints)] as an earlier kernel of
-    // the iteration left them (replay_tables_to_global): one coalesced load instead of recomputing them in every workgroup
-    const float *tables;
-    int tablesStride;          // floats between two frames' tables (a batch), else 0
-    // a batch: a workgroup walks several tiles (the staging of its prologue paid once) yet leaves ONE partial system per TILE, at
-    // the tile's index -- the slabs, hence every sum, are those of a launch with one workgroup per tile
-    int slabPerTile;
-};
-
 // a batch's replay tables: one workgroup per frame leaves what replay_tables_to_global computes for the frame's pose
 __global__ void __launch_bounds__(NE_BLOCK)
 replay_tables_kernel(ModelView m_in, float flx, float fly, float ppx, float ppy, int width, int height, float *__restrict__ tables, int stride) {
@@ -468,7 +466,7 @@ replay_tables_kernel(ModelView m_in, float flx, float fly, float ppx, float ppy,
     replay_tables_to_global(m, flx, fly, ppx, ppy, width, height, lds, tables + (size_t)blockIdx.x * stride);
 }
 
-template <int PPT, int RED, bool TRUNC, bool REPLAY = false>
+template <int PPT, int RED, bool TRUNC, int REPLAY = 0>       // REPLAY: 0 reads the map, 1 forms it from its model's traces, 2 from every model's
 __device__ __forceinline__ void ne_mod2obs_body(const float4 *__restrict__ pred, int nPix, int modelNum, ModelView m_in, const float *__restrict__ T_gc_in,
                   float truncationDist, int redDims, const float *__restrict__ dtheta_dalpha, const int *__restrict__ mapping,
                   float *__restrict__ slabs, int *__restrict__ numPredictions, ReplayArgs ra, FrameBatch fb, int tgcStride,
@@ -508,7 +506,9 @@ __device__ __forceinline__ void ne_mod2obs_body(const float4 *__restrict__ pred,
     // Everything the workgroup stages is requested before anything is waited for: the frame transforms, the replay tables and
     // the first tile's prediction pixel travel together (one memory round trip; a loop of load -> LDS store pays one per turn)
     constexpr int QS = 4;
-    const int nT = 12 * m.nFrames, nTab = (REPLAY && ra.tables) ? 28 * m.nSdfs + 1 : 0;
+    int nTabAll = 28 * m.nSdfs + 1;
+    if (REPLAY == 2) { nTabAll = 0; for (int mi = 0; mi < ra.multi->nModels; ++mi) nTabAll += 28 * ra.multi->nSdfsOf[mi] + 1; }
+    const int nT = 12 * m.nFrames, nTab = (REPLAY && ra.tables) ? nTabAll : 0;
     const bool batched = nT <= QS * NE_BLOCK && nTab <= QS * NE_BLOCK;
     float4 pcFirst = make_float4(0.f, 0.f, 0.f, 0.f);
     if (REPLAY && ra.predOut && bx * NE_BLOCK + (int)threadIdx.x < nPix) pcFirst = ra.predOut[bx * NE_BLOCK + threadIdx.x];
@@ -565,7 +565,28 @@ __device__ __forceinline__ void ne_mod2obs_body(const float4 *__restrict__ pred,
         int frame = 0;
         if (index < nPix) {
             float4 pc;
-            if (REPLAY) {       // the pixel's prediction is formed here from the per-SDF traces and kept for the caller
+            if (REPLAY == 2) {
+                const ReplayMulti &mu = *ra.multi;
+                pc = (tile == (int)bx || !ra.predOut) ? pcFirst : ra.predOut[index];
+                pc.z = 0; pc.w = -1;                     // model 0 starts the map (x, y keep what the map held)
+                const int px = index % ra.width, py = index / ra.width;
+                int off = 0;
+                for (int mi = 0; mi < mu.nModels; ++mi) {
+                    const int n = mu.nSdfsOf[mi];
+                    float closestT = 10000;
+                    replay_pixel<24>(pc, closestT, px, py, n, reinterpret_cast<const int *>(sRT + off + 24 * n), mi, 0, n, sRT + off,
+                                     reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(ra.trace) + mu.traceOff[mi]),
+                                     ra.flx, ra.fly, ra.ppx, ra.ppy);
+                    off += 28 * n + 1;
+                }
+                if (pc.z != 0) {                         // cullUnobservable only ever clears z
+                    const int height = nPix / ra.width;
+                    const int ox = px * mu.ow / ra.width, oy = py * mu.oh / height;
+                    const int oi = ox + oy * mu.ow;
+                    if (mu.obs[oi].w <= 0 || mu.obs[oi + 1].w <= 0 || mu.obs[oi + mu.ow].w <= 0 || mu.obs[oi + mu.ow + 1].w <= 0) pc.z = 0;
+                }
+                if (mu.writesMap && ra.predOut) ra.predOut[index] = pc;
+            } else if (REPLAY) {       // the pixel's prediction is formed here from the per-SDF traces and kept for the caller
                 // (no map: model 0 of a loop that returns no prediction -- the replay starts every pixel from "no hit" anyway)
                 pc = (tile == (int)bx || !ra.predOut) ? pcFirst : ra.predOut[index];
                 M2O_STAMP(2);
@@ -630,7 +651,7 @@ __device__ __forceinline__ void ne_mod2obs_body(const float4 *__restrict__ pred,
 #endif
 }
 
-template <int PPT, int RED, bool TRUNC, bool REPLAY = false>
+template <int PPT, int RED, bool TRUNC, int REPLAY = 0>
 __global__ void __launch_bounds__(NE_BLOCK)
 ne_mod2obs_kernel(const float4 *__restrict__ pred, int nPix, int modelNum, ModelView m_in, const float *__restrict__ T_gc_in,
                   float truncationDist, int redDims, const float *__restrict__ dtheta_dalpha, const int *__restrict__ mapping,
@@ -679,14 +700,23 @@ union_terms_kernel(const UnionTable *__restrict__ t) {
         else if (g.red == 1) ne_intersection_body<PPT, 1>(g.sites, g.nSites, g.m, g.m2, nullptr, g.redDims, g.A, g.map, g.slabs, 0, bx, gx, 0);
         else ne_intersection_body<PPT, 2>(g.sites, g.nSites, g.m, g.m2, nullptr, g.redDims, g.A, g.map, g.slabs, 0, bx, gx, 0);
         break;
+    case UK_TABLES:
+        replay_tables_to_global(g.m, g.flx, g.fly, g.ppx, g.ppy, g.width, g.height, lds, g.slabs);
+        break;
     default: break;
     }
     } else {
     switch (g.kind) {
     case UK_M2O:
-        if (g.red == 0) ne_mod2obs_body<PPT, 0, false, false>(g.pred, g.nPred, g.m.modelId, g.m, g.T_gc, 0.f, g.redDims, g.A, g.map, g.slabs, g.numPredictions, ReplayArgs{}, one, 0, nullptr, bx, gx, 0);
-        else if (g.red == 1) ne_mod2obs_body<PPT, 1, false, false>(g.pred, g.nPred, g.m.modelId, g.m, g.T_gc, 0.f, g.redDims, g.A, g.map, g.slabs, g.numPredictions, ReplayArgs{}, one, 0, nullptr, bx, gx, 0);
-        else ne_mod2obs_body<PPT, 2, false, false>(g.pred, g.nPred, g.m.modelId, g.m, g.T_gc, 0.f, g.redDims, g.A, g.map, g.slabs, g.numPredictions, ReplayArgs{}, one, 0, nullptr, bx, gx, 0);
+        if (g.replay.tables) {      // the replay of every model's traces and the cull happen in the term itself: no launch between
+            if (g.red == 0) ne_mod2obs_body<PPT, 0, false, 2>(g.pred, g.nPred, g.m.modelId, g.m, g.T_gc, 0.f, g.redDims, g.A, g.map, g.slabs, g.numPredictions, g.replay, one, 0, nullptr, bx, gx, 0);
+            else if (g.red == 1) ne_mod2obs_body<PPT, 1, false, 2>(g.pred, g.nPred, g.m.modelId, g.m, g.T_gc, 0.f, g.redDims, g.A, g.map, g.slabs, g.numPredictions, g.replay, one, 0, nullptr, bx, gx, 0);
+            else ne_mod2obs_body<PPT, 2, false, 2>(g.pred, g.nPred, g.m.modelId, g.m, g.T_gc, 0.f, g.redDims, g.A, g.map, g.slabs, g.numPredictions, g.replay, one, 0, nullptr, bx, gx, 0);
+            break;
+        }
+        if (g.red == 0) ne_mod2obs_body<PPT, 0, false, 0>(g.pred, g.nPred, g.m.modelId, g.m, g.T_gc, 0.f, g.redDims, g.A, g.map, g.slabs, g.numPredictions, ReplayArgs{}, one, 0, nullptr, bx, gx, 0);
+        else if (g.red == 1) ne_mod2obs_body<PPT, 1, false, 0>(g.pred, g.nPred, g.m.modelId, g.m, g.T_gc, 0.f, g.redDims, g.A, g.map, g.slabs, g.numPredictions, ReplayArgs{}, one, 0, nullptr, bx, gx, 0);
+        else ne_mod2obs_body<PPT, 2, false, 0>(g.pred, g.nPred, g.m.modelId, g.m, g.T_gc, 0.f, g.redDims, g.A, g.map, g.slabs, g.numPredictions, ReplayArgs{}, one, 0, nullptr, bx, gx, 0);
         break;
     default:        // UK_O2M
         if (g.red == 0) ne_obs2mod_body<PPT, 0>(g.pts, g.vert, g.nPix, g.m, g.huberDelta, g.redDims, g.A, g.map, g.slabs, g.count_, one, bx, gx, 0);
@@ -815,7 +845,7 @@ int gn_launch_raycast_trace_at(float flx, float fly, float ppx, float ppy, int w
 }
 int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float ppy, int width, int height, int nModels,
                                         Model *const *mods, const size_t *bufOffsets, float *d_prediction, const float *d_obs, int ow,
-                                        int oh, hipStream_t st, int *d_hitCount) {
+                                        int oh, hipStream_t st, int *d_hitCount, const float *d_tables) {
     Workspace *ws;
     int rc = get_workspace(&ws);
     if (rc) return rc;
@@ -836,7 +866,13 @@ int gn_launch_raycast_replay_cull_multi(float flx, float fly, float ppx, float p
         perFrame = perFrame < 1 ? 1 : (perFrame > nChunks ? nChunks : perFrame);
         hipLaunchKernelGGL(raycast_replay_multi_rows_kernel, dim3(perFrame, cur_batch().n), dim3(256), ldsFloats * sizeof(float), st, flx, fly,
                            ppx, ppy, width, height, a, (const float *)ws->rayBuf, (float4 *)d_prediction, (const float4 *)d_obs, ow, oh, cur_batch(),
-                           d_hitCount);
+                           d_hitCount, (const float *)nullptr, 0);
+    } else if (d_tables && cur_batch().n == 1 && ldsFloats * sizeof(float) <= 64 * 1024) {
+        // a single frame whose tables the launch before has left in memory: a workgroup per 256-pixel chunk, the caller's map kept
+        DARTK_REQUIRE(!d_hitCount, "the hit-list form of the replay is the batch's");
+        hipLaunchKernelGGL(raycast_replay_multi_rows_kernel, dim3(nChunks, 1), dim3(256), ldsFloats * sizeof(float), st, flx, fly,
+                           ppx, ppy, width, height, a, (const float *)ws->rayBuf, (float4 *)d_prediction, (const float4 *)d_obs, ow, oh, cur_batch(),
+                           (int *)nullptr, d_tables, 1);
     } else {
         DARTK_REQUIRE(!d_hitCount, "the hit-list form of the replay needs the batch kernel (gn_replay_hit_lists)");
         hipLaunchKernelGGL(raycast_replay_multi_kernel, dim3((unsigned)nChunks, cur_batch().n), dim3(256), 0, st, flx, fly, ppx, ppy, width, height,

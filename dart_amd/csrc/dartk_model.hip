@@ -61,7 +61,8 @@ int get_workspace(Workspace **out) {
 // fills the next slot, uploads it asynchronously and marks it released once its last consumer is enqueued. The host only ever
 // waits when the ring has wrapped around onto a slot whose consumer has not finished -- eight calls ahead of the device.
 static constexpr int kArgSlots = 8;
-static constexpr size_t kArgSlotBytes = 16384;
+static constexpr size_t kArgSlotBytes = 65536;
+size_t arg_slot_bytes() { return kArgSlotBytes; }
 struct ArgRing { char *d; char *h; hipEvent_t ev[kArgSlots]; bool used[kArgSlots]; int next; bool ready; };
 static ArgRing g_argRing[16];
 int arg_ring_acquire(size_t bytes, ArgSlot *out) {

@@ -449,6 +449,12 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     size_t total = argBytes + sizeof(int) * cntInts + sizeof(float) * floatsSmall + 1024;
     const size_t o_union = (total + 255) / 256 * 256;          // two UnionTable blocks (the single-frame loop's shared launches)
     total = o_union + 2 * ((sizeof(UnionTable) + 255) / 256 * 256);
+    // the models' ray-cast tables of the current pose ([transforms | tile rectangles], 28 nSdfs + 1 words each), written by the
+    // first shared launch of an iteration for the replay that follows it
+    const size_t o_rtab = total;
+    size_t rtabFloats = 0, rtabOff[DARTK_MAX_MODELS];
+    for (int m = 0; m < n; ++m) { rtabOff[m] = rtabFloats; rtabFloats += 28 * (size_t)mods[m]->v.nSdfs + 1; }
+    total = o_rtab + (sizeof(float) * rtabFloats + 255) / 256 * 256;
     size_t o_pose = 0, o_obs = 0, o_tmp = 0, o_pred = 0, o_pts = 0;
     if (batch) {
         auto take = [&](size_t bytes) { size_t at = (total + 255) / 256 * 256; total = at + bytes; return at; };
@@ -538,15 +544,62 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     h.zeroA = useA ? d_countA : nullptr; h.zeroB = useB ? d_countB : nullptr;
     h.itCounter = d_itCounter;
     h.fb = fb; h.redStride = batch ? redTotal : 0; h.infoStride = batch ? (size_t)o->numIterations * n * 8 : 0; h.T_mcs = d_T_mcs;
+    // generateObsSdf per model with its start pose (optimizer.cpp:574-580); the full-pose mod->obs wrapper works in that frame.
+    // A single frame: the builds of the first two models are the longest part of the call's set-up and depend on nothing else in
+    // it (each model has its own volumes), so they go FIRST, on the two side streams, and the caller's stream meanwhile takes the
+    // argument blocks, the tables and the valid-pixel lists; the three are joined before the loop.
+    const bool sideBuilds = useB && !batch && n > 1 && !prof_enabled() && getenv("DARTK_MULTI_ONE_STREAM") == nullptr;
+    auto build_obs_sdf = [&](int m, hipStream_t sb) -> int {
+        ProfScope ps(DARTK_PROF_OBS_SDF, sb);
+        int rc = gn_obs_sdf_build(d_vert, width, height, mods[m], o->focalLength, sb);
+        if (rc == DARTK_OK && hipMemcpy2DAsync(T_obs[m], sizeof(float) * (batch ? tabStride : 12), mods[m]->v.T_mc,
+                                               sizeof(float) * (batch ? mods[m]->v.poseStride : 12), 12 * sizeof(float), nFrames,
+                                               hipMemcpyDeviceToDevice, sb) != hipSuccess) {
+            set_error("copy of the observation-SDF pose failed");
+            rc = DARTK_ERR_HIP;
+        }
+        return rc;
+    };
+    struct BuildJoin {      // (also on an error return: the caller's stream stays ordered after the side streams)
+        Workspace *w; hipStream_t st; bool on;
+        void join() {
+            if (!on) return;
+            on = false;
+            (void)hipEventRecord(w->evObs, w->auxStream); (void)hipEventRecord(w->evJoin2, w->auxStream2);
+            (void)hipStreamWaitEvent(st, w->evObs, 0); (void)hipStreamWaitEvent(st, w->evJoin2, 0);
+        }
+        ~BuildJoin() { join(); }
+    } buildJoin{ws, st, false};
+    if (sideBuilds) {
+        DARTK_HIP(hipEventRecord(ws->evFork, st));
+        DARTK_HIP(hipStreamWaitEvent(ws->auxStream, ws->evFork, 0));
+        DARTK_HIP(hipStreamWaitEvent(ws->auxStream2, ws->evFork, 0));
+        buildJoin.on = true;
+        for (int m = 0; m < 2; ++m) {
+            rc = build_obs_sdf(m, m == 0 ? ws->auxStream : ws->auxStream2);
+            if (rc) return rc;
+        }
+    }
+    bool oneCopy = false;
     {   // argument block and tables leave through a pinned slot: the call does not wait for the stream
+        // (a single frame: the block, the zeroed counters behind it and the tables behind those lie back to back on the device and
+        // leave as ONE copy; a batch's counters are per frame and are cleared by a memset of their own)
         ArgSlot slot;
-        rc = arg_ring_acquire(sizeof(h) + sizeof(float) * tables.size(), &slot);
+        const size_t cntBytes = sizeof(int) * cntInts, tabBytes = sizeof(float) * tables.size();
+        oneCopy = !batch && argBytes + cntBytes + tabBytes <= arg_slot_bytes();
+        rc = arg_ring_acquire(oneCopy ? argBytes + cntBytes + tabBytes : sizeof(h) + tabBytes, &slot);
         if (rc) return rc;
         memcpy(slot.h, &h, sizeof(h));
-        float *hTab = reinterpret_cast<float *>((char *)slot.h + sizeof(h));
-        if (!tables.empty()) memcpy(hTab, tables.data(), sizeof(float) * tables.size());
-        DARTK_HIP(hipMemcpyAsync(d_args, slot.h, sizeof(h), hipMemcpyHostToDevice, st));
-        if (!tables.empty()) DARTK_HIP(hipMemcpyAsync(fl, hTab, sizeof(float) * tables.size(), hipMemcpyHostToDevice, st));
+        if (oneCopy) {
+            memset((char *)slot.h + sizeof(h), 0, argBytes - sizeof(h) + cntBytes);
+            if (tabBytes) memcpy((char *)slot.h + argBytes + cntBytes, tables.data(), tabBytes);
+            DARTK_HIP(hipMemcpyAsync(d_args, slot.h, argBytes + cntBytes + tabBytes, hipMemcpyHostToDevice, st));
+        } else {
+            float *hTab = reinterpret_cast<float *>((char *)slot.h + sizeof(h));
+            if (tabBytes) memcpy(hTab, tables.data(), tabBytes);
+            DARTK_HIP(hipMemcpyAsync(d_args, slot.h, sizeof(h), hipMemcpyHostToDevice, st));
+            if (tabBytes) DARTK_HIP(hipMemcpyAsync(fl, hTab, tabBytes, hipMemcpyHostToDevice, st));
+        }
         rc = arg_ring_release(slot, st);
         if (rc) return rc;
     }
@@ -588,33 +641,11 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         rc = gn_valid_pixels(d_vert, nPix, nFrames, d_work, d_validIdx, d_nValid, st);
         if (rc) return rc;
     }
-    // generateObsSdf per model with its start pose (optimizer.cpp:574-580); the full-pose mod->obs wrapper works in that frame
-    if (useB) {
-        // a single frame: the builds of the models are independent (each has its own volumes): the first runs here, the others
-        // beside it on a side stream, joined before the loop
-        const bool sideBuilds = !batch && n > 1 && !prof_enabled() && getenv("DARTK_MULTI_ONE_STREAM") == nullptr;
-        if (sideBuilds) {
-            DARTK_HIP(hipEventRecord(ws->evFork, st));
-            DARTK_HIP(hipStreamWaitEvent(ws->auxStream, ws->evFork, 0));
+    if (useB)
+        for (int m = sideBuilds ? 2 : 0; m < n; ++m) {
+            rc = build_obs_sdf(m, st);
+            if (rc) return rc;
         }
-        for (int m = 0; m < n; ++m) {
-            hipStream_t sb = (sideBuilds && m > 0) ? ws->auxStream : st;
-            ProfScope ps(DARTK_PROF_OBS_SDF, sb);
-            rc = gn_obs_sdf_build(d_vert, width, height, mods[m], o->focalLength, sb);
-            if (rc == DARTK_OK && hipMemcpy2DAsync(T_obs[m], sizeof(float) * (batch ? tabStride : 12), mods[m]->v.T_mc,
-                                                   sizeof(float) * (batch ? mods[m]->v.poseStride : 12), 12 * sizeof(float), nFrames,
-                                                   hipMemcpyDeviceToDevice, sb) != hipSuccess) {
-                set_error("copy of the observation-SDF pose failed");
-                rc = DARTK_ERR_HIP;
-            }
-            if (rc) break;
-        }
-        if (sideBuilds) {       // (also on an error: the caller's stream stays ordered after the side stream)
-            (void)hipEventRecord(ws->evObs, ws->auxStream);
-            (void)hipStreamWaitEvent(st, ws->evObs, 0);
-        }
-        if (rc) return rc;
-    }
     // Three chains per iteration meet only in the solve: ray-cast -> cull -> mod->obs (the longest, on the caller's stream),
     // association -> obs->mod, and the intersection terms; the two shorter ones run on the side streams, each term wrapper
     // writing its partial systems into its chain's lane of the slab buffer.
@@ -643,7 +674,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         }
     } joinGuard{ws, st, stA, stC, false};
     // both counter arrays start at zero; every solve launch leaves them cleared for the next iteration
-    DARTK_HIP(hipMemsetAsync(d_countA, 0, 2 * (size_t)DARTK_MAX_MODELS * nFrames * sizeof(int), st));
+    if (!oneCopy) DARTK_HIP(hipMemsetAsync(d_countA, 0, 2 * (size_t)DARTK_MAX_MODELS * nFrames * sizeof(int), st));
     // ---- the single-frame loop on ONE stream with shared launches (the C2 recipe): per iteration
     //   [trace of every model | association | self- and pairwise intersection terms]  ->  replay + cull
     //   ->  [mod->obs of every model | obs->mod of every model]  ->  one reduction of all partial systems  ->  solve
@@ -653,6 +684,8 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     UnionTable *d_u1 = reinterpret_cast<UnionTable *>((char *)base + o_union);
     UnionTable *d_u2 = reinterpret_cast<UnionTable *>((char *)base + o_union + (sizeof(UnionTable) + 255) / 256 * 256);
     int u1Blocks = 0, u2Blocks = 0, unionPpt = 1, nUnionJobs = 0;
+    bool useTables = false, fuseReplay = false;
+    float *d_rtab = reinterpret_cast<float *>((char *)base + o_rtab);
     size_t u1Lds = 0, u2Lds = 0;
     ReduceJob unionJobs[kMaxReduceJobs];
     bool unionPath = !batch && n <= 3 && o->numIterations > 0 && nPriors >= 0 && getenv("DARTK_MULTI_NO_UNION") == nullptr &&
@@ -728,6 +761,19 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
                 if (u1Lds < l) u1Lds = l;
             }
         }
+        // (last in the grid: short workgroups that are done long before the trace's stragglers)
+        useTables = useB && t1.nSeg + n <= kMaxUnionSegs && getenv("DARTK_MULTI_NO_RAY_TABLES") == nullptr;
+        // with the tables in memory, and few enough of them to stage beside a term's own data, the mod->obs terms form the
+        // prediction themselves (each from every model's traces, the first model's term writing the map): no replay launch
+        fuseReplay = useTables && rtabFloats <= 4 * NE_BLOCK && getenv("DARTK_MULTI_REPLAY_LAUNCH") == nullptr;
+        for (int m = 0; m < n && useTables; ++m) {
+            const ModelView &v = mods[m]->v;
+            UnionSeg &g = seg(t1, u1Blocks, UK_TABLES, 1);
+            g.m = v; g.flx = o->predFl[0]; g.fly = o->predFl[1]; g.ppx = (float)(o->predWidth / 2); g.ppy = (float)(o->predHeight / 2);
+            g.width = o->predWidth; g.height = o->predHeight;
+            g.slabs = d_rtab + rtabOff[m];
+            if (u1Lds < sizeof(float) * (28 * (size_t)v.nSdfs + 1)) u1Lds = sizeof(float) * (28 * (size_t)v.nSdfs + 1);
+        }
         for (int m = 0; m < n; ++m) {
             const MultiSolveModel &sm = h.m[m];
             const ModelView &v = mods[m]->v;
@@ -738,7 +784,22 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
                 g.T_gc = sm.redType == 0 ? T_obs[m] : v.T_mc;        // (reduced wrappers use the model's current T_mc, modToObs.cu:851-988)
                 g.numPredictions = d_countB + m; g.redDims = sm.dims; g.A = mm[m].d_A; g.map = mm[m].d_map;
                 slab(g, sys_size(sm.dims), sysB[m], nullptr, 1, 0);
-                const size_t l = ne_mod2obs_lds_bytes(v, sm.dims, sm.redType);
+                size_t l = ne_mod2obs_lds_bytes(v, sm.dims, sm.redType);
+                if (fuseReplay) {       // raytracePrediction's replay + cullUnobservable (:610-618) inside the term
+                    ReplayArgs &r = g.replay;
+                    r.flx = o->predFl[0]; r.fly = o->predFl[1]; r.ppx = (float)(o->predWidth / 2); r.ppy = (float)(o->predHeight / 2);
+                    r.width = o->predWidth; r.modelNum = m;
+                    r.trace = reinterpret_cast<const float2 *>(ws->rayBuf);
+                    r.predOut = (float4 *)d_prediction;
+                    r.tables = d_rtab; r.tablesStride = 0; r.slabPerTile = 0;
+                    ReplayMulti &mu = g.replayMulti;
+                    mu.nModels = n;
+                    for (int k = 0; k < n; ++k) { mu.nSdfsOf[k] = mods[k]->v.nSdfs; mu.traceOff[k] = traceOff[k]; }
+                    mu.obs = (const float4 *)d_vert; mu.ow = width; mu.oh = height;
+                    mu.writesMap = m == 0;
+                    r.multi = &d_u2->seg[t2.nSeg - 1].replayMulti;        // (the member's address in the device copy of the table)
+                    l += sizeof(float) * rtabFloats;
+                }
                 if (u2Lds < l) u2Lds = l;
             }
             if (useA) {
@@ -754,18 +815,21 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         if (rc) return rc;
         for (UnionTable *t : {&t1, &t2})
             for (int i = 0; i < t->nSeg; ++i)
-                if (t->seg[i].kind >= UK_SELF) t->seg[i].slabs = ws->partials + reinterpret_cast<size_t>(t->seg[i].slabs);
+                if (t->seg[i].kind >= UK_SELF && t->seg[i].kind != UK_TABLES) t->seg[i].slabs = ws->partials + reinterpret_cast<size_t>(t->seg[i].slabs);
         for (int i = 0; i < nUnionJobs; ++i) unionJobs[i].slabs = ws->partials + reinterpret_cast<size_t>(unionJobs[i].slabs);
-        for (int k = 0; k < 2; ++k) {
+        {   // the two tables lie back to back on the device: one copy
+            const size_t stride = (sizeof(UnionTable) + 255) / 256 * 256;
             ArgSlot slot;
-            rc = arg_ring_acquire(sizeof(UnionTable), &slot);
+            rc = arg_ring_acquire(stride + sizeof(UnionTable), &slot);
             if (rc) return rc;
-            memcpy(slot.h, k == 0 ? &t1 : &t2, sizeof(UnionTable));
-            DARTK_HIP(hipMemcpyAsync(k == 0 ? d_u1 : d_u2, slot.h, sizeof(UnionTable), hipMemcpyHostToDevice, st));
+            memcpy(slot.h, &t1, sizeof(UnionTable));
+            memcpy((char *)slot.h + stride, &t2, sizeof(UnionTable));
+            DARTK_HIP(hipMemcpyAsync(d_u1, slot.h, stride + sizeof(UnionTable), hipMemcpyHostToDevice, st));
             rc = arg_ring_release(slot, st);
             if (rc) return rc;
         }
     }
+    buildJoin.join();           // the observation SDFs are ready on the caller's stream from here on
     auto run_union_iteration = [&](int it) -> int {
         int rc = DARTK_OK;
         if (u1Blocks > 0) {
@@ -773,10 +837,10 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
             rc = gn_launch_union(d_u1, u1Blocks, unionPpt, 0, u1Lds, st);
             if (rc) return rc;
         }
-        if (useB) {
+        if (useB && !fuseReplay) {
             const float ppx = (float)(o->predWidth / 2), ppy = (float)(o->predHeight / 2);
             rc = gn_launch_raycast_replay_cull_multi(o->predFl[0], o->predFl[1], ppx, ppy, o->predWidth, o->predHeight, n, mods, traceOff,
-                                                     d_prediction, d_vert, width, height, st, nullptr);
+                                                     d_prediction, d_vert, width, height, st, nullptr, useTables ? d_rtab : nullptr);
             if (rc) return rc;
         }
         if (u2Blocks > 0) {

@@ -157,8 +157,10 @@ class Tracker:
             self.updatePose(m)
             p, red = self.poses[m], self.red_dev[m]
             ra_n = p.getReducedArticulatedDimensions()
-            ra = torch.from_numpy(np.ascontiguousarray(p.getReducedArticulation(), dtype=F).reshape(-1)[:ra_n].copy()).to(dev) if ra_n else \
-                torch.zeros(1, dtype=torch.float32, device=dev)
+            # (through pinned memory, without waiting: a copy from pageable memory would hold the host until the stream -- the
+            # previous frame's loop -- has drained, and the next frame's set-up could not be enqueued behind it)
+            ra = torch.from_numpy(np.ascontiguousarray(p.getReducedArticulation(), dtype=F).reshape(-1)[:ra_n].copy()).pin_memory() \
+                .to(dev, non_blocking=True) if ra_n else torch.zeros(1, dtype=torch.float32, device=dev)
             red_art.append(ra)
             mins = np.asarray([p.getReducedMin(i) for i in range(ra_n)] or [0.0], dtype=F)
             maxs = np.asarray([p.getReducedMax(i) for i in range(ra_n)] or [0.0], dtype=F)
