@@ -724,6 +724,8 @@ def main():
             n_s = min(len(f_idx), 8)
             for m in range(2):
                 mtr.getPose(m).setTransformCameraToModel(mT0[0, m])
+            mtr.getPose(0).getReducedArticulation()[:] = ma0[0]
+            mtr.optimizePosesDevice(mvert[0], mnorm[0], readback=False)         # one untimed frame (first-call set-up of this path)
             torch.cuda.synchronize()
             ts0 = time.perf_counter()
             for k in range(n_s):

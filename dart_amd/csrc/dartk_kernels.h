@@ -34,6 +34,7 @@ struct BatchScope {         // sets the current batch for a scope
 struct ArgSlot { void *d; void *h; int idx, dev; };
 size_t arg_slot_bytes();
 int arg_ring_acquire(size_t bytes, ArgSlot *out);
+int arg_ring_upload(void *d_dst, const ArgSlot &s, size_t bytes, hipStream_t st);      // slot -> device, by a kernel (never holds the host)
 int arg_ring_release(const ArgSlot &s, hipStream_t st);
 int ensure_partials(Workspace *w, size_t floats);
 void registry_add(Model *m);           // dartk_tables.hip: live model handles by their device arrays

@@ -84,6 +84,21 @@ int arg_ring_acquire(size_t bytes, ArgSlot *out) {
     out->d = r.d + (size_t)i * kArgSlotBytes; out->h = r.h + (size_t)i * kArgSlotBytes; out->idx = i; out->dev = dev;
     return DARTK_OK;
 }
+// slot -> device memory by a kernel that reads the pinned slot (mapped into the device's address space). hipMemcpyAsync holds the
+// HOST until the stream has drained for copies beyond a few KB (measured on ROCm 7.2: the 34 KB of launch tables of the
+// multi-model loop kept every call in step with the device, 680 us per call); a kernel launch never waits.
+__global__ void __launch_bounds__(256)
+upload_words_kernel(unsigned *__restrict__ dst, const unsigned *__restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int arg_ring_upload(void *d_dst, const ArgSlot &s, size_t bytes, hipStream_t st) {
+    DARTK_REQUIRE(bytes % 4 == 0 && bytes <= kArgSlotBytes, "arg_ring_upload: %zu bytes", bytes);
+    const size_t n = bytes / 4;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
+    hipLaunchKernelGGL(upload_words_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, (unsigned *)d_dst, (const unsigned *)s.h, n);
+    DARTK_HIP(hipGetLastError());
+    return DARTK_OK;
+}
 int arg_ring_release(const ArgSlot &s, hipStream_t st) {
     ArgRing &r = g_argRing[s.dev];
     DARTK_HIP(hipEventRecord(r.ev[s.idx], st));

@@ -53,19 +53,41 @@ struct MultiSolveArgs {
     int *itCounter;         // every solve leaves its iteration number + 1 here (read by a launch with iteration == -3)
 };
 
+// the rows of the reduction a lane needs for its joint (pose.cpp:66-73, 91-97), loaded ahead of the solve like the FK tables
+static constexpr int kRedPrefetch = 8;
+struct RedTables { float b, A[kRedPrefetch]; int map; };
+__device__ __forceinline__ RedTables red_prefetch(const MultiSolveModel &m, const ModelView &v) {
+    const int lane = threadIdx.x & 63;
+    RedTables t;
+    t.b = 0.0f; t.map = 0;
+#pragma unroll
+    for (int r = 0; r < kRedPrefetch; ++r) t.A[r] = 0.0f;
+    if (lane < v.nJoints) {
+        if (m.redType == 2) t.map = m.map[lane];
+        else if (m.redType == 1) {
+            t.b = m.b[lane];
+#pragma unroll
+            for (int r = 0; r < kRedPrefetch; ++r) if (r < m.redArt) t.A[r] = m.A[r + lane * m.redArt];
+        }
+    }
+    return t;
+}
 // projection of the reduced articulation in ra[] (LDS) to the full joint vector (pose.cpp:66-73, 91-97) and forward
 // kinematics (Tracker::updatePose) of one model; one wave. `t`: the model's constant joint / frame tables (fk_prefetch), loaded by
 // the caller ahead of the work the new joint values wait for. Joint j belongs to lane j, which is the lane that moves frame j + 1:
 // its value goes into the kinematics in a register, the store to v.joints is for the kernels that follow.
-__device__ __forceinline__ void project_and_fk(const MultiSolveModel &m, const ModelView &v, const float *ra, float *sT, const FkTables &t) {
+__device__ __forceinline__ void project_and_fk(const MultiSolveModel &m, const ModelView &v, const float *ra, float *sT, const FkTables &t,
+                                               const RedTables &rt) {
     const int lane = threadIdx.x & 63;
     float full = 0.0f;
     if (lane < v.nJoints) {
         if (m.redType == 0) full = ra[lane];
-        else if (m.redType == 2) full = ra[m.map[lane]];
+        else if (m.redType == 2) full = ra[rt.map];
         else {
-            full = m.b[lane];
-            for (int r = 0; r < m.redArt; ++r) full = full + ra[r] * m.A[r + lane * m.redArt];      // pose.cpp:66-73
+            full = rt.b;
+#pragma unroll
+            for (int r = 0; r < kRedPrefetch; ++r) if (r < m.redArt) full = full + ra[r] * rt.A[r];                 // pose.cpp:66-73
+            for (int r = kRedPrefetch; r < m.redArt; ++r) full = full + ra[r] * m.A[r + lane * m.redArt];
         }
         v.joints[lane] = full;
     }
@@ -201,6 +223,7 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration, int fkF
             return;
         }
         const FkTables tab = fk_prefetch(v);
+        const RedTables rtab = red_prefetch(m, v);
         if (lane == 0) {
             float T[12], Tinv[12];
             for (int i = 0; i < 12; ++i) T[i] = T_io[i];
@@ -209,7 +232,7 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration, int fkF
         }
         if (lane < m.redArt) ra[lane] = m.redArtPtr[(size_t)frame * a.redStride + lane];
         wave_sync_lds();
-        project_and_fk(m, v, ra, sT, tab);
+        project_and_fk(m, v, ra, sT, tab, rtab);
         return;
     }
 #ifdef DARTK_STAMPS
@@ -217,6 +240,7 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration, int fkF
 #endif
     // what the update at the end needs and the solution does not change: in flight from here on
     const FkTables tab = fk_prefetch(v);
+    const RedTables rtab = red_prefetch(m, v);
     float T_old[12];
     if (mine && lane == 0)
         for (int i = 0; i < 12; ++i) T_old[i] = v.T_mc[i];
@@ -354,7 +378,7 @@ multi_solve_kernel(const MultiSolveArgs *__restrict__ ap, int iteration, int fkF
             ra[lane] = c;
         }
         wave_sync_lds();
-        project_and_fk(m, v, ra, sT, tab);
+        project_and_fk(m, v, ra, sT, tab, rtab);
     }
     // this iteration's counts have been read (summaries above, the gated reductions before this launch): ready for the next
     if (threadIdx.x < DARTK_MAX_MODELS) {       // (the arrays hold DARTK_MAX_MODELS counters per frame in either form of the loop)
@@ -593,7 +617,8 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         if (oneCopy) {
             memset((char *)slot.h + sizeof(h), 0, argBytes - sizeof(h) + cntBytes);
             if (tabBytes) memcpy((char *)slot.h + argBytes + cntBytes, tables.data(), tabBytes);
-            DARTK_HIP(hipMemcpyAsync(d_args, slot.h, argBytes + cntBytes + tabBytes, hipMemcpyHostToDevice, st));
+            rc = arg_ring_upload(d_args, slot, argBytes + cntBytes + tabBytes, st);
+            if (rc) return rc;
         } else {
             float *hTab = reinterpret_cast<float *>((char *)slot.h + sizeof(h));
             if (tabBytes) memcpy(hTab, tables.data(), tabBytes);
@@ -603,7 +628,6 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
         rc = arg_ring_release(slot, st);
         if (rc) return rc;
     }
-
     const int ldU = (D + 1) | 1;
     const int fkFloats = 12 * maxFrames + 8;          // forward-kinematics scratch of one wave (= model)
     const size_t ldsSolve = sizeof(float) * ((size_t)2 * D * ldU + 2 * D + (size_t)n * (64 + fkFloats));
@@ -802,8 +826,9 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
                 }
                 if (u2Lds < l) u2Lds = l;
             }
+            static const int o2mWgs = getenv("DARTK_UNION_O2M_WGS") ? atoi(getenv("DARTK_UNION_O2M_WGS")) : 512;
             if (useA) {
-                UnionSeg &g = seg(t2, u2Blocks, UK_O2M, tilesPix < 512 ? tilesPix : 512);
+                UnionSeg &g = seg(t2, u2Blocks, UK_O2M, tilesPix < o2mWgs ? tilesPix : o2mWgs);
                 g.red = sm.redType; g.m = v; g.pts = ptsList[m]; g.vert = (const float4 *)d_vert; g.nPix = nPix; g.huberDelta = o->huberDelta;
                 g.count_ = d_countA + m; g.redDims = sm.dims; g.A = mm[m].d_A; g.map = mm[m].d_map;
                 slab(g, sys_size(sm.dims), sysA[m], d_countA + m, 0, 10);
@@ -824,12 +849,15 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
             if (rc) return rc;
             memcpy(slot.h, &t1, sizeof(UnionTable));
             memcpy((char *)slot.h + stride, &t2, sizeof(UnionTable));
-            DARTK_HIP(hipMemcpyAsync(d_u1, slot.h, stride + sizeof(UnionTable), hipMemcpyHostToDevice, st));
+            rc = arg_ring_upload(d_u1, slot, stride + sizeof(UnionTable), st);
+            if (rc) return rc;
             rc = arg_ring_release(slot, st);
             if (rc) return rc;
         }
     }
-    buildJoin.join();           // the observation SDFs are ready on the caller's stream from here on
+    // the observation SDFs are first read by the mod->obs terms: the shared-launch form joins the builds behind its first launch
+    // (trace, association, intersections), which runs beside them; the three-stream form before its loop
+    if (!unionPath) buildJoin.join();
     auto run_union_iteration = [&](int it) -> int {
         int rc = DARTK_OK;
         if (u1Blocks > 0) {
@@ -837,6 +865,7 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
             rc = gn_launch_union(d_u1, u1Blocks, unionPpt, 0, u1Lds, st);
             if (rc) return rc;
         }
+        buildJoin.join();       // (first iteration only)
         if (useB && !fuseReplay) {
             const float ppx = (float)(o->predWidth / 2), ppy = (float)(o->predHeight / 2);
             rc = gn_launch_raycast_replay_cull_multi(o->predFl[0], o->predFl[1], ppx, ppy, o->predWidth, o->predHeight, n, mods, traceOff,

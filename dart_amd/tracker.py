@@ -60,6 +60,7 @@ class Tracker:
         self.opts.distThreshold, self.opts.planeOffset, self.opts.planeNormal = [], [], []
         self.priors = []
         self.damping = []     # per model: [dims, dims] damping matrix (getDampingMatrix), zero at first
+        self._ra_ring = []    # per model: pinned staging slots of the reduced articulation (_upload_red_art)
         dev = torch.device("cuda", torch.cuda.current_device())
         self.prediction = torch.zeros((self.pred_height, self.pred_width, 4), dtype=torch.float32, device=dev)
         self.iteration_summaries = None
@@ -76,6 +77,33 @@ class Tracker:
         """Tracker::getDampingMatrix (tracker.h:122): the [dims, dims] matrix added to the model's block of the normal equations
         after the regularisation and the LM scaling (optimizer.cpp:702-703); modify it in place."""
         return self.damping[model_num]
+
+    _RA_SLOTS = 8
+
+    def _upload_red_art(self, m, values, dev):
+        """Model m's reduced articulation as a fresh device array, uploaded through the model's ring of pinned slots without
+        waiting: a copy from pageable memory would hold the host until the stream -- the previous frame's loop -- has drained, and
+        the next frame's set-up could not be enqueued behind it. (The ring is made when the model is added; a slot is reused
+        once the copy that last read it has run.)"""
+        ring = self._ra_ring[m]
+        k = ring["next"]
+        ring["next"] = (k + 1) % self._RA_SLOTS
+        if ring["ev"][k] is not None:
+            ring["ev"][k].synchronize()
+        slot = ring["pin"][k, :len(values)]
+        slot.copy_(torch.from_numpy(values))
+        out = slot.to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring["ev"][k] = ev
+        return out
+
+    def _zero1(self, dev):
+        """a one-float device array for models without articulation (allocated and cleared once, not per call)"""
+        z = getattr(self, "_zero1_dev", None)
+        if z is None or z.device != torch.device(dev):
+            z = self._zero1_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        return z
 
     def _damping_dev(self, m, keep):
         """device pointer of model m's damping matrix, None while it is zero"""
@@ -97,6 +125,8 @@ class Tracker:
         self.poses.append(Pose(red))
         rd = 6 + red.getReducedDimensions()
         self.damping.append(np.zeros((rd, rd), dtype=F))      # _dampingMatrices.push_back(Zero(...)) (tracker.cpp:246-247)
+        self._ra_ring.append({"pin": torch.empty((self._RA_SLOTS, max(rd - 6, 1)), dtype=torch.float32).pin_memory(),
+                              "ev": [None] * self._RA_SLOTS, "next": 0})
         if red.isNull():
             self.red_dev.append(None)
         elif red.isParamMap():
@@ -157,10 +187,8 @@ class Tracker:
             self.updatePose(m)
             p, red = self.poses[m], self.red_dev[m]
             ra_n = p.getReducedArticulatedDimensions()
-            # (through pinned memory, without waiting: a copy from pageable memory would hold the host until the stream -- the
-            # previous frame's loop -- has drained, and the next frame's set-up could not be enqueued behind it)
-            ra = torch.from_numpy(np.ascontiguousarray(p.getReducedArticulation(), dtype=F).reshape(-1)[:ra_n].copy()).pin_memory() \
-                .to(dev, non_blocking=True) if ra_n else torch.zeros(1, dtype=torch.float32, device=dev)
+            ra = self._upload_red_art(m, np.ascontiguousarray(p.getReducedArticulation(), dtype=F).reshape(-1)[:ra_n], dev) if ra_n \
+                else self._zero1(dev)
             red_art.append(ra)
             mins = np.asarray([p.getReducedMin(i) for i in range(ra_n)] or [0.0], dtype=F)
             maxs = np.asarray([p.getReducedMax(i) for i in range(ra_n)] or [0.0], dtype=F)
