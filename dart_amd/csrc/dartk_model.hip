@@ -175,6 +175,15 @@ reduce_slabs_kernel(const float *__restrict__ slabs, int nBlocks, int S, float *
     double s = 0.0;
     if (keep && o < S) {
         int b = seg;
+        // (sixteen loads in flight, added in slab order: the sums are those of the plain loop, the chain of round trips a quarter
+        // of what four at a time leave -- this kernel's duration is that chain)
+        for (; b + 15 * kReduceSegs < nBlocks; b += 16 * kReduceSegs) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = slabs[(size_t)(b + k * kReduceSegs) * S + o];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += (double)v[k];
+        }
         for (; b + 3 * kReduceSegs < nBlocks; b += 4 * kReduceSegs) {
             const float v0 = slabs[(size_t)b * S + o];
             const float v1 = slabs[(size_t)(b + kReduceSegs) * S + o];
@@ -209,6 +218,15 @@ reduce_slabs_jobs_kernel(ReduceJobTable t, FrameBatch fb) {
     double s = 0.0;
     if (keep && o < S) {        // the sums of reduce_slabs_kernel, term for term
         int b = seg;
+        // (sixteen loads in flight, added in slab order: the sums are those of the plain loop, the chain of round trips a quarter
+        // of what four at a time leave -- this kernel's duration is that chain)
+        for (; b + 15 * kReduceSegs < nBlocks; b += 16 * kReduceSegs) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = slabs[(size_t)(b + k * kReduceSegs) * S + o];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += (double)v[k];
+        }
         for (; b + 3 * kReduceSegs < nBlocks; b += 4 * kReduceSegs) {
             const float v0 = slabs[(size_t)b * S + o];
             const float v1 = slabs[(size_t)(b + kReduceSegs) * S + o];
