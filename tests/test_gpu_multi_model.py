@@ -217,3 +217,33 @@ def test_shared_launch_form_equals_three_stream_form(gpu, monkeypatch):
         n_red = len(pu[m][1])
         if n_red:
             assert np.abs(tr._red_art_dev[m].cpu().numpy()[:n_red] - pu[m][1]).max() < 1e-3
+
+
+def test_prediction_map_of_the_fused_replay_is_the_replay_launch_s(gpu, monkeypatch):
+    """In the shared-launch form the mod->obs terms form the prediction themselves (replay of every model's traces in model
+    order, then cullUnobservable; the first model's term writes the map). After ONE iteration from the same start poses the
+    map the caller gets must be, bit for bit, the map of the replay + cull launch -- in the shared-launch form with that launch
+    kept (DARTK_MULTI_REPLAY_LAUNCH) and in the three-stream form (DARTK_MULTI_NO_UNION) -- and so must the mod->obs counts."""
+    sc, tr, vert, norm = setup(640, 360, 1)
+
+    def run_once():
+        for m, (T, a) in enumerate(sc.init):
+            tr.getPose(m).setTransformCameraToModel(T)
+            tr.getPose(m).getReducedArticulation()[:] = a
+        tr.prediction.zero_()
+        tr.optimizePosesDevice(vert, norm, debug=True)
+        return tr.prediction.cpu().numpy().copy(), tr.iteration_summaries.copy()
+
+    fused, i_f = run_once()
+    monkeypatch.setenv("DARTK_MULTI_REPLAY_LAUNCH", "1")
+    launch, i_l = run_once()
+    monkeypatch.delenv("DARTK_MULTI_REPLAY_LAUNCH")
+    monkeypatch.setenv("DARTK_MULTI_NO_UNION", "1")
+    streams, i_s = run_once()
+    monkeypatch.delenv("DARTK_MULTI_NO_UNION")
+    hits = fused[..., 2] != 0
+    assert hits.sum() > 500 and len(np.unique(fused[..., 3][hits].astype(np.int64) >> 16)) == 2       # both models are seen
+    assert fused.tobytes() == launch.tobytes()
+    assert fused.tobytes() == streams.tobytes()
+    assert np.array_equal(i_f[:, :, 4], i_l[:, :, 4]) and np.array_equal(i_f[:, :, 4], i_s[:, :, 4]) and i_f[0, :, 4].min() > 50
+
