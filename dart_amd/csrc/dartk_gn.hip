@@ -992,7 +992,7 @@ int dartk_optimize_pose(dartk_model_t h, const float *d_vert, const float *d_nor
     const int nPred = o->predWidth * o->predHeight;
     const int tilesB = (nPred + NE_BLOCK - 1) / NE_BLOCK;
     static const char *envB = getenv("DARTK_M2O_TILES_PER_WG");       // diagnostic: tiles per mod->obs workgroup
-    const int tpw = envB ? atoi(envB) : 1;
+    const int tpw = (envB && atoi(envB) > 0) ? atoi(envB) : 1;
     const int wantB = (tilesB + tpw - 1) / tpw;
     const int nBlocksB = wantB < GN_MAX_BLOCKS ? wantB : GN_MAX_BLOCKS;
     const int tilesC = (nCloud + NE_BLOCK - 1) / NE_BLOCK;

@@ -269,7 +269,7 @@ static int launch_raycast_trace(float flx, float fly, float ppx, float ppy, int 
     // one task per wave and pass); a single frame gets enough workgroups for the whole chip, a batch shares it among its frames
     // (measured sweep on 64 frames, tools/time_batch_replay.sh: 24-96 per frame equal, 192 +2 %, 384 +7 %)
     static const char *envT = getenv("DARTK_TRACE_WGS");      // diagnostic override: workgroups per frame of a batch
-    const long long want = cur_batch().n > 1 ? (envT ? atoi(envT) : 64) : 1024;
+    const long long want = cur_batch().n > 1 ? ((envT && atoi(envT) > 0) ? atoi(envT) : 64) : 1024;
     const unsigned blocks = (unsigned)((tasks + 3) / 4 < want ? (tasks + 3) / 4 : want);
     ProfScope ps(DARTK_PROF_RAYCAST, st);
     hipLaunchKernelGGL(raycast_trace_kernel, dim3(blocks, cur_batch().n), dim3(256), 0, st, flx, fly, ppx, ppy, width, height, m,

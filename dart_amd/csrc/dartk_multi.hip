@@ -826,7 +826,12 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
                 }
                 if (u2Lds < l) u2Lds = l;
             }
-            static const int o2mWgs = getenv("DARTK_UNION_O2M_WGS") ? atoi(getenv("DARTK_UNION_O2M_WGS")) : 512;
+            // (diagnostic override, tools/time_single_loop.py sweeps it: 128 / 256 cost 8-25 % of the loop, 1024 is equal, 2048 -4 %)
+            static const int o2mWgs = [] {
+                const char *e = getenv("DARTK_UNION_O2M_WGS");
+                const int v = e ? atoi(e) : 0;
+                return (v >= 1 && v <= kMaxPartialBlocks) ? v : 512;
+            }();
             if (useA) {
                 UnionSeg &g = seg(t2, u2Blocks, UK_O2M, tilesPix < o2mWgs ? tilesPix : o2mWgs);
                 g.red = sm.redType; g.m = v; g.pts = ptsList[m]; g.vert = (const float4 *)d_vert; g.nPix = nPix; g.huberDelta = o->huberDelta;
