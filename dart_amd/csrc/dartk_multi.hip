@@ -465,8 +465,9 @@ static int optimize_poses_impl(const dartk_multi_options *o, const dartk_multi_m
     fb.trace = traceFloats;
     if (!batch) fb = FrameBatch{1, 0, 0, 0, 0, 0, 0, 0};
 
-    // one allocation: [args | countA | countB | shared tables | per-frame tables | per-frame systems] and, for a batch,
-    // [poses | observation SDFs | distance-transform scratch | prediction maps | association lists]
+    // one allocation: [args | countA | countB | shared tables | per-frame tables | per-frame systems | the two launch tables |
+    // the models' ray-cast tables] and, for a batch, [poses | observation SDFs | distance-transform scratch | prediction maps |
+    // association lists]
     const size_t argBytes = (sizeof(MultiSolveArgs) + 255) / 256 * 256;
     const size_t cntInts = 2 * (size_t)DARTK_MAX_MODELS * nFrames + 4;      // + the iteration counter
     size_t floatsSmall = tableFloats + (size_t)nFrames * (tabStride + sysFloats);
