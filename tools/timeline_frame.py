@@ -9,7 +9,7 @@ for r in csv.DictReader(open(kf)):
 mf = glob.glob(os.path.dirname(kf) + "/*_memory_copy_trace.csv")
 if mf:
     for r in csv.DictReader(open(mf[0])):
-        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy %s %s B" % (r.get("Direction", "?"), r.get("Bytes", "?"))))
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy engine: %s" % r.get("Direction", "?")))
 ev.sort()
 solves = [i for i, e in enumerate(ev) if "multi_solve_kernel" in e[2]]
 # frames are 10 solves apart; take the boundary between the third-last and second-last frame
