@@ -719,7 +719,7 @@ def main():
         barrier()
         m_elapsed = max_over_ranks(time.perf_counter() - t0)
         # the same frames one at a time through the single-frame device loop (what round 1 measured), on a sample
-        single_its = None
+        single_its = single_its_carried = None
         if rank == 0:
             n_s = min(len(f_idx), 8)
             for m in range(2):
@@ -735,6 +735,12 @@ def main():
                 mtr.optimizePosesDevice(mvert[k], mnorm[k], readback=False)     # poses stay on the device between frames
             torch.cuda.synchronize()
             single_its = n_s * m_iters / (time.perf_counter() - ts0)
+            # the same calls as a tracker makes them: every frame starts from the poses the previous call left on the device
+            ts1 = time.perf_counter()
+            for k in range(n_s):
+                mtr.optimizePosesDevice(mvert[k], mnorm[k], readback=False, from_device=True)
+            torch.cuda.synchronize()
+            single_its_carried = n_s * m_iters / (time.perf_counter() - ts1)
             # ---- roofline of this leg: HIP-event durations of one batch step with the three chains on ONE stream (side by side
             # on three streams every kernel's duration is stretched by the others and says nothing), the lookups its kernels
             # perform counted by the diagnostic library on a sample of the frames, algorithmic bytes per kernel class and step
@@ -818,12 +824,13 @@ def main():
                      "value": round(n_frames * args.multi_steps * m_iters / m_elapsed, 2),
                      "frames_per_s": round(n_frames * args.multi_steps / m_elapsed, 2), "scaling": "strong", "n_frames": n_frames,
                      "frames_per_gpu": len(f_idx), "steps": args.multi_steps, "ms_per_step": round(1000.0 * m_elapsed / args.multi_steps, 3),
-                     "iterations_per_step": m_iters, "single_frame_loop_GN_its": round(single_its, 2), "dtype": "f32", "data": "synthetic",
+                     "iterations_per_step": m_iters, "single_frame_loop_GN_its": round(single_its, 2), "single_frame_loop_from_device_GN_its": round(single_its_carried, 2) if single_its_carried else None, "dtype": "f32", "data": "synthetic",
                      "roofline": m_roof, "cpu_baseline": m_cpu,
                      "config": {"workload": "BASELINE configs[4]: %d frames of Barrett hand (8 joints reduced to 4, proxy geometry) + box object, "
                                             "synthetic 1280x720 depth per frame, obs->mod + mod->obs + self / pairwise intersection in reduced "
                                             "dimensions, %d GN iterations per frame, frames sharded by index over %d GPU(s), one all-gather of "
-                                            "the poses; single_frame_loop_GN_its = the same frames one call at a time" % (n_frames, m_iters, world)}}
+                                            "the poses; single_frame_loop_GN_its = the same frames one call at a time, each from its own uploaded start pose; "
+                                            "..._from_device_... = each from the poses the previous call left on the device" % (n_frames, m_iters, world)}}
 
     if rank == 0:
         value = world * n_steps * iters / elapsed if n_steps else 0.0

@@ -170,10 +170,12 @@ class Tracker:
         self.models[m].set_pose(p.getTransformCameraToModel(), p.getArticulation())
 
     # ---- Optimizer::optimizePoses (optimizer.cpp:524-781), device-resident (dartk_optimize_poses)
-    def optimizePosesDevice(self, vert, norm, debug=False, readback=True):
+    def optimizePosesDevice(self, vert, norm, debug=False, readback=True, from_device=False):
         """The whole loop in one library call: no host round trip per term or per iteration. Poses come back at the end
         (readback=False: they stay on the device -- the models' device poses and the returned reduced articulations hold the
-        result -- and the call does not wait for the stream; a caller that tracks frame after frame reads them when it needs them)."""
+        result -- and the call does not wait for the stream; readPoses() fetches them when the caller needs them).
+        from_device=True starts from what the previous call left on the device instead of uploading the host-side poses: a
+        tracker that runs frame after frame with readback=False, from_device=True never moves a pose across the bus."""
         import ctypes as C
         from . import _abi
         from ._abi import check, lib
@@ -183,12 +185,18 @@ class Tracker:
         mm = (_abi.MultiModelC * n)()
         keep = []
         red_art = []
+        carried = getattr(self, "_red_art_dev", None) if from_device else None
+        if from_device and (carried is None or len(carried) != n):
+            raise ValueError("from_device=True needs the poses a previous optimizePosesDevice call left on the device")
         for m in range(n):
-            self.updatePose(m)
             p, red = self.poses[m], self.red_dev[m]
             ra_n = p.getReducedArticulatedDimensions()
-            ra = self._upload_red_art(m, np.ascontiguousarray(p.getReducedArticulation(), dtype=F).reshape(-1)[:ra_n], dev) if ra_n \
-                else self._zero1(dev)
+            if carried is not None:
+                ra = carried[m]
+            else:
+                self.updatePose(m)
+                ra = self._upload_red_art(m, np.ascontiguousarray(p.getReducedArticulation(), dtype=F).reshape(-1)[:ra_n], dev) if ra_n \
+                    else self._zero1(dev)
             red_art.append(ra)
             mins = np.asarray([p.getReducedMin(i) for i in range(ra_n)] or [0.0], dtype=F)
             maxs = np.asarray([p.getReducedMax(i) for i in range(ra_n)] or [0.0], dtype=F)
@@ -242,7 +250,19 @@ class Tracker:
         self._red_art_dev = red_art
         if not readback:
             return
-        for m in range(n):      # the poses live on the device during the loop; mirror them back once
+        self.readPoses()
+        if debug:
+            self.iteration_summaries = info.cpu().numpy()
+            self.first_system = first.cpu().numpy()
+        return -1.0
+
+    def readPoses(self):
+        """Mirrors the poses the last optimizePosesDevice call left on the device into the host-side Pose objects (waits for
+        the device)."""
+        red_art = getattr(self, "_red_art_dev", None)
+        if red_art is None:
+            return
+        for m in range(len(self.models)):      # the poses live on the device during the loop; mirror them back once
             T_mc = self.models[m].get_T_mc()
             p = self.poses[m]
             p.setTransformCameraToModel(T_mc)
@@ -250,10 +270,6 @@ class Tracker:
             if ra_n:
                 p.getReducedArticulation()[:ra_n] = red_art[m].cpu().numpy()[:ra_n]
             p.projectReducedToFull()
-        if debug:
-            self.iteration_summaries = info.cpu().numpy()
-            self.first_system = first.cpu().numpy()
-        return -1.0
 
     # ---- a batch of independent frames (BASELINE configs[4]), dartk_optimize_poses_batch
     def optimizePosesBatch(self, vert, norm, T_mcs, red_arts, debug=False):

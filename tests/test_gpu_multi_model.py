@@ -247,3 +247,44 @@ def test_prediction_map_of_the_fused_replay_is_the_replay_launch_s(gpu, monkeypa
     assert fused.tobytes() == streams.tobytes()
     assert np.array_equal(i_f[:, :, 4], i_l[:, :, 4]) and np.array_equal(i_f[:, :, 4], i_s[:, :, 4]) and i_f[0, :, 4].min() > 50
 
+
+def test_tracking_from_the_poses_left_on_the_device(gpu):
+    """Three frames in a row, each starting where the one before ended: with every call reading the poses back and uploading
+    them again, and with the poses never leaving the device (readback=False, then from_device=True; readPoses() at the end).
+    The uploads carry the same bits the device held, so the two must agree to the rounding the association lists' run-to-run
+    order allows."""
+    sc, tr, vert, norm = setup(640, 360, 4)
+
+    def start():
+        for m, (T, a) in enumerate(sc.init):
+            tr.getPose(m).setTransformCameraToModel(T)
+            tr.getPose(m).getReducedArticulation()[:] = a
+
+    def poses():
+        return [(tr.getPose(m).getTransformCameraToModel().copy(), tr.getPose(m).getReducedArticulation().copy()) for m in range(2)]
+
+    start()
+    for _ in range(3):
+        tr.optimizePosesDevice(vert, norm)
+    host = poses()
+    start()
+    tr.optimizePosesDevice(vert, norm, readback=False)
+    for _ in range(2):
+        tr.optimizePosesDevice(vert, norm, readback=False, from_device=True)
+    stale = poses()
+    for m, (T, a) in enumerate(sc.init):        # nothing has come back yet: the host still holds the start poses
+        assert np.array_equal(stale[m][0], np.asarray(T, dtype=np.float32).reshape(stale[m][0].shape))
+    tr.readPoses()
+    dev = poses()
+    moved = 0.0
+    for m in range(2):
+        dt, dr = pose_diff(dev[m][0], host[m][0])
+        assert dt < 1e-5 and dr < 1e-3, (m, dt, dr)
+        if len(host[m][1]):
+            assert np.abs(dev[m][1] - host[m][1]).max() < 1e-3
+        moved = max(moved, pose_diff(dev[m][0], stale[m][0])[0])
+    assert moved > 1e-4                         # the frames did move the poses
+    tr2 = setup(640, 360, 4)[1]
+    with pytest.raises(ValueError):
+        tr2.optimizePosesDevice(vert, norm, from_device=True)
+

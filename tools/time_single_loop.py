@@ -1,6 +1,6 @@
 """Where a frame of the config-5 single-frame loop (Tracker.optimizePosesDevice, readback=False) spends its time: the loop as
 bench.py runs it (every frame starts from its own host-side start pose), the same without the per-frame pose upload (a tracker
-carries the pose over), and the host's share of a call."""
+carries the pose over on the device: from_device=True), and the host's share of a call."""
 import sys, os, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -25,7 +25,7 @@ for mode in ("reset every frame (bench.py)", "pose carried over"):
         for k in range(N):
             if mode.startswith("reset"): reset()
             h0 = time.perf_counter()
-            tr.optimizePosesDevice(vert, norm, readback=False)
+            tr.optimizePosesDevice(vert, norm, readback=False, from_device=not mode.startswith("reset"))
             host += time.perf_counter() - h0
         hostAll = time.perf_counter() - t0
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
